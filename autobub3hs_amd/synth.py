@@ -1,0 +1,171 @@
+"""Seeded, integer-only synthetic PICO-like events (SURVEY.md section 8d generator).
+
+Every value is produced with int64 +,*,>>,&,^,% only, so numpy (CPU tests, golden fixtures) and
+torch (bench: frames generated straight into HBM) give bit-identical frames.
+
+Scene: smooth background + fixed-pattern noise per camera, per-frame noise = sum of four U{-1,0,1}
+draws (sigma ~1.6 ADU), optional whole-frame LED flicker (+3 ADU on one frame), and bubbles:
+discs of radius 2+1.5k px at frame t0+k with +-40 ADU contrast.
+"""
+import numpy as np
+
+BASE_SEED = 0xAB0B3
+
+
+def _hash32(x):
+    """32-bit integer mix on int64 arrays (values stay < 2**59: no overflow, numpy == torch)."""
+    x = x & 0xFFFFFFFF
+    x = ((x ^ (x >> 16)) * 0x45D9F3B) & 0xFFFFFFFF
+    x = ((x ^ (x >> 16)) * 0x45D9F3B) & 0xFFFFFFFF
+    x = x ^ (x >> 16)
+    return x
+
+
+def _hash32_scalar(v):
+    v &= 0xFFFFFFFF
+    v = ((v ^ (v >> 16)) * 0x45D9F3B) & 0xFFFFFFFF
+    v = ((v ^ (v >> 16)) * 0x45D9F3B) & 0xFFFFFFFF
+    return v ^ (v >> 16)
+
+
+class _NP:
+    int64 = np.int64
+
+    @staticmethod
+    def arange(n, device=None):
+        return np.arange(n, dtype=np.int64)
+
+    @staticmethod
+    def where(c, a, b):
+        return np.where(c, a, b)
+
+    @staticmethod
+    def clip(a, lo, hi):
+        return np.clip(a, lo, hi)
+
+    @staticmethod
+    def to_u8(a):
+        return a.astype(np.uint8)
+
+    @staticmethod
+    def empty_u8(shape, device=None):
+        return np.empty(shape, np.uint8)
+
+
+class _TORCH:
+    def __init__(self):
+        import torch
+
+        self.t = torch
+        self.int64 = torch.int64
+
+    def arange(self, n, device=None):
+        return self.t.arange(n, dtype=self.t.int64, device=device)
+
+    def where(self, c, a, b):
+        return self.t.where(c, a, b)
+
+    def clip(self, a, lo, hi):
+        return self.t.clamp(a, lo, hi)
+
+    def to_u8(self, a):
+        return a.to(self.t.uint8)
+
+    def empty_u8(self, shape, device=None):
+        return self.t.empty(shape, dtype=self.t.uint8, device=device)
+
+
+def _backend(xp):
+    return _TORCH() if xp == "torch" else _NP()
+
+
+def background(W, H, cam_seed, xp="numpy", device=None):
+    """B(y,x) as int64 [H,W] (not yet clipped)."""
+    be = _backend(xp)
+    x = be.arange(W, device)[None, :]
+    y = be.arange(H, device)[:, None]
+    t = x % 74
+    tri = be.where(t < 37, t, 74 - t)
+    fixed = _hash32((((y * W + x) * 2654435761) & 0xFFFFFFFF) ^ _hash32_scalar(cam_seed * 7919 + 1)) % 5 - 2
+    return 40 + (x * 60) // W + (y * 30) // H + (12 * tri) // 37 + fixed
+
+
+def frame_noise(W, H, frame_seed, xp="numpy", device=None):
+    """Sum of four U{-1,0,1} draws per pixel, int64 [H,W]."""
+    be = _backend(xp)
+    x = be.arange(W, device)[None, :]
+    y = be.arange(H, device)[:, None]
+    s = _hash32_scalar(frame_seed)
+    h = _hash32((((y * W + x) * 2654435761) & 0xFFFFFFFF) ^ s)
+    n = (h & 0xFF) % 3 + ((h >> 8) & 0xFF) % 3 + ((h >> 16) & 0xFF) % 3 + ((h >> 24) & 0xFF) % 3
+    return n - 4
+
+
+class EventSpec:
+    """What happens in one (event, camera) stack."""
+
+    def __init__(self, F, t0=None, bubbles=(), flicker=None, flicker_adu=3):
+        self.F = F
+        self.t0 = t0            # genesis frame index (None: no bubble -> status -3)
+        self.bubbles = list(bubbles)  # [(cx, cy, contrast)]
+        self.flicker = flicker  # frame index with +flicker_adu on the whole frame, or None
+        self.flicker_adu = flicker_adu
+
+
+def random_spec(W, H, F, event, cam, p_second=0.2, p_none=0.0, p_flicker=0.0, margin=40):
+    """Deterministic spec from (event, cam) -- host-side, tiny."""
+    rs = np.random.RandomState((BASE_SEED + event * 1000 + cam) & 0x7FFFFFFF)
+    if rs.rand() < p_none:
+        return EventSpec(F)
+    lo, hi = 10, max(11, F - 15)
+    t0 = int(rs.randint(lo, hi))
+    nb = 2 if rs.rand() < p_second else 1
+    bubbles = []
+    for _ in range(nb):
+        cx = int(rs.randint(margin, W - margin))
+        cy = int(rs.randint(margin, H - margin))
+        contrast = -40 if rs.rand() < 0.5 else 40
+        bubbles.append((cx, cy, contrast))
+    flicker = None
+    if rs.rand() < p_flicker:
+        flicker = int(rs.randint(3, max(4, t0 - 3))) if t0 > 6 else None
+    return EventSpec(F, t0, bubbles, flicker)
+
+
+def render_event(W, H, spec, event, cam, xp="numpy", device=None, out=None, bg=None):
+    """-> uint8 [F,H,W] stack (numpy array or torch tensor on `device`)."""
+    be = _backend(xp)
+    if bg is None:
+        bg = background(W, H, BASE_SEED + cam, xp, device)
+    if out is None:
+        out = be.empty_u8((spec.F, H, W), device)
+    x = be.arange(W, device)[None, :]
+    y = be.arange(H, device)[:, None]
+    ev_seed = BASE_SEED + event * 1000 + cam
+    for f in range(spec.F):
+        v = bg + frame_noise(W, H, ev_seed * 131 + f, xp, device)
+        if spec.flicker is not None and f == spec.flicker:
+            v = v + spec.flicker_adu
+        if spec.t0 is not None and f >= spec.t0:
+            k = f - spec.t0
+            r2 = (4 + 3 * k) * (4 + 3 * k)  # (2*(2+1.5k))^2, compare in doubled coordinates
+            for (cx, cy, contrast) in spec.bubbles:
+                dx = 2 * (x - cx)
+                dy = 2 * (y - cy)
+                inside = (dx * dx + dy * dy) <= r2
+                v = be.where(inside, v + contrast, v)
+        out[f] = be.to_u8(be.clip(v, 0, 255))
+    return out
+
+
+def training_pairs(W, H, n_events, cam, F, xp="numpy", device=None, **kw):
+    """Frames 0 and 1 of events 0..n_events-1 (quiet by construction) -> uint8 [2*n,H,W]."""
+    be = _backend(xp)
+    out = be.empty_u8((2 * n_events, H, W), device)
+    bg = background(W, H, BASE_SEED + cam, xp, device)
+    for e in range(n_events):
+        ev_seed = BASE_SEED + e * 1000 + cam
+        for f in (0, 1):
+            v = bg + frame_noise(W, H, ev_seed * 131 + f, xp, device)
+            out[2 * e + f] = be.to_u8(be.clip(v, 0, 255))
+    return out
