@@ -1,0 +1,849 @@
+// abub_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the bubble-detection hot path
+// and their stateless C-ABI launchers (include/abub_hip.h, layer A).
+//
+// Kernel inventory (DESIGN.md section "Kernels"):
+//   K2  k2_rows<NDW,STORE>   fused AnalyzerUnit::ProcessFrame + 256-bin histogram, register-rolling rows
+//   K2g k2_generic           same arithmetic, any size / ROI, LDS tile (also the ROI overload)
+//   K1  k1_welford           Trainer::CalculateMeanSigmaImageVector (float32 Welford, no FMA)
+//   K1b k1b_pair_hist        histogram of sat(f1 - f0) (training entropy veto)
+//   K3  k3_generic           post-trigger |f-mu|-6sigma, 3x3 box, histogram
+//   K4  k4_compact           binarize + foreground index compaction
+// No MFMA anywhere: this is integer/byte pixel work (see DESIGN.md "Why no MFMA").
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/abub_hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[256] = "";
+int abub_set_err_(int code, const char *what, hipError_t e);
+
+extern "C" const char *abub_last_error(void) { return g_err; }
+
+int abub_set_err_(int code, const char *what, hipError_t e)
+{
+    if (e != hipSuccess)
+        snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    else
+        snprintf(g_err, sizeof g_err, "%s", what);
+    return code;
+}
+static int set_err(int code, const char *what, hipError_t e = hipSuccess) { return abub_set_err_(code, what, e); }
+#define HIPCHK(x)                                   \
+    do {                                            \
+        hipError_t e_ = (x);                        \
+        if (e_ != hipSuccess)                       \
+            return set_err(ABUB_E_HIP, #x, e_);     \
+    } while (0)
+
+extern "C" int abub_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+extern "C" int abub_device_info(int device, char *name, int name_cap, int *cus, uint64_t *hbm_bytes)
+{
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, device));
+    if (name && name_cap > 0)
+        snprintf(name, name_cap, "%s (%s)", p.name, p.gcnArchName);
+    if (cus)
+        *cus = p.multiProcessorCount;
+    if (hbm_bytes)
+        *hbm_bytes = p.totalGlobalMem;
+    return ABUB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+// cv::borderInterpolate(BORDER_REFLECT_101)
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1)
+        return 0;
+    while (p < 0 || p >= len)
+        p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+// two u16 lanes, saturating unsigned subtract  (v_pk_sub_u16 ... clamp)
+__device__ __forceinline__ uint32_t pk_subsat(uint32_t a, uint32_t b)
+{
+    u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(x, y));
+}
+// two i16 lanes, |a-b|  (2x v_pk_sub_i16 + v_pk_max_i16)
+__device__ __forceinline__ uint32_t pk_absdiff(uint32_t a, uint32_t b)
+{
+    s16x2 x = __builtin_bit_cast(s16x2, a), y = __builtin_bit_cast(s16x2, b);
+    s16x2 d = x - y, e = y - x;
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(d, e));
+}
+// two u16 lanes: a*6 + b  (v_pk_mad_u16)
+__device__ __forceinline__ uint32_t pk_mad6(uint32_t a, uint32_t b)
+{
+    u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
+    u16x2 six = {6, 6};
+    return __builtin_bit_cast(uint32_t, (u16x2)(x * six + y));
+}
+
+// bytes (b0,b1) / (b2,b3) of a dword widened to two u16 lanes  (v_perm_b32)
+__device__ __forceinline__ uint32_t widen_lo(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c010c00u); }
+__device__ __forceinline__ uint32_t widen_hi(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c030c02u); }
+
+// ------------------------------------------------------------------------------------------------
+// sigma6 = min(6*sigma, 255)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_sigma6(const uint8_t *__restrict__ s, uint8_t *__restrict__ o, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        int v = 6 * (int)s[i];
+        o[i] = (uint8_t)(v > 255 ? 255 : v);
+    }
+}
+
+extern "C" int abub_sigma6_dev(const uint8_t *sigma, uint8_t *sigma6, size_t n, void *stream)
+{
+    if (!sigma || !sigma6)
+        return set_err(ABUB_E_INVALID, "abub_sigma6_dev: null pointer");
+    if (n == 0)
+        return ABUB_OK;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096)
+        blocks = 4096;
+    hipLaunchKernelGGL(k_sigma6, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sigma, sigma6, n);
+    HIPCHK(hipGetLastError());
+    return ABUB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// job list for regular stacks
+// ------------------------------------------------------------------------------------------------
+__global__ void k_fill_stack_jobs(abub_job *jobs, int nstacks, int F, int first, int count, int off,
+                                  int nmodels)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nstacks * count)
+        return;
+    int s = j / count, n = j % count;
+    int i = first + n;
+    int r = i - off;
+    if (r < 0)
+        r = 0;
+    abub_job jb;
+    jb.cur = (uint32_t)(s * F + i);
+    jb.ref = (uint32_t)(s * F + r);
+    jb.model = (uint32_t)(s % nmodels);
+    jb.out = (uint32_t)j;
+    jobs[j] = jb;
+}
+
+extern "C" int abub_fill_stack_jobs_dev(abub_job *jobs, int nstacks, int F, int first, int count,
+                                        int ref_offset, int nmodels, void *stream)
+{
+    if (!jobs || nstacks < 0 || F <= 0 || first < 0 || count < 0 || first + count > F ||
+        ref_offset < 0 || nmodels <= 0)
+        return set_err(ABUB_E_INVALID, "abub_fill_stack_jobs_dev: bad arguments");
+    int n = nstacks * count;
+    if (n == 0)
+        return ABUB_OK;
+    hipLaunchKernelGGL(k_fill_stack_jobs, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       jobs, nstacks, F, first, count, ref_offset, nmodels);
+    HIPCHK(hipGetLastError());
+    return ABUB_OK;
+}
+
+// hist[slot][0] = P - sum(hist[slot][1..255])  (the kernels only count non-zero pixels)
+__global__ __launch_bounds__(64) void k_hist_bin0(uint32_t *hist, uint32_t P)
+{
+    uint32_t *h = hist + (size_t)blockIdx.x * 256;
+    int l = threadIdx.x;
+    uint32_t s = h[l + 64] + h[l + 128] + h[l + 192] + (l ? h[l] : 0u);
+    for (int o = 32; o > 0; o >>= 1)
+        s += __shfl_xor(s, o);
+    if (l == 0)
+        h[0] = P - s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 fast: register-rolling rows.
+//
+// One wave (64-thread workgroup) owns output rows [y0,y1) of one job.  Lane L holds 4*NDW consecutive
+// pixels of a row (blocked mapping), the wave spans the whole row: W == 4*NDW*nl, nl <= 64 lanes.
+// Per input row: 3*NDW dword loads/lane (cur, ref, sigma6) -> saturating differences on u16 pairs
+// (two pixels per 32-bit register, pos plane and neg plane) -> horizontal 1-4-6-4-1 with the two
+// neighbour pairs fetched from the adjacent lanes by DPP wave shifts (reflect-101 in-lane at the
+// image edges) -> vertical 1-4-6-4-1 as four in-place accumulators per pair (no ring rotation)
+// -> (S+128)>>8 via byte permute, |pos-neg|, LDS histogram of the (rare) non-zero pixels, optional store.
+// Every u16 lane stays < 65536: H <= 4080+8, V <= 16*4088 = 65408.
+// ------------------------------------------------------------------------------------------------
+#define DPP_WAVE_SHL1 0x130 /* lane i <- lane i+1 */
+#define DPP_WAVE_SHR1 0x138 /* lane i <- lane i-1 */
+
+template <int NDW>
+struct RowIn {
+    uint32_t c[NDW], r[NDW], s[NDW];
+};
+
+template <int NDW>
+__device__ __forceinline__ void k2_load_row(RowIn<NDW> &R, const uint8_t *__restrict__ cur,
+                                            const uint8_t *__restrict__ ref,
+                                            const uint8_t *__restrict__ sg, int y, int W, int xoff,
+                                            bool active)
+{
+    if (active) {
+        size_t o = (size_t)y * W + xoff;
+        const uint32_t *pc = reinterpret_cast<const uint32_t *>(cur + o);
+        const uint32_t *pr = reinterpret_cast<const uint32_t *>(ref + o);
+        const uint32_t *ps = reinterpret_cast<const uint32_t *>(sg + o);
+#pragma unroll
+        for (int d = 0; d < NDW; d++) {
+            R.c[d] = pc[d];
+            R.r[d] = pr[d];
+            R.s[d] = ps[d];
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < NDW; d++)
+            R.c[d] = R.r[d] = R.s[d] = 0;
+    }
+}
+
+// persistent per-wave state of the vertical pass: four in-place accumulators per u16 pair and plane
+// out = a0 + X ; a0 = a1 + 4X ; a1 = a2 + 6X ; a2 = xp + 4X ; xp = X
+template <int NDW>
+struct K2Acc {
+    uint32_t pa0[2 * NDW], pa1[2 * NDW], pa2[2 * NDW], pxp[2 * NDW];
+    uint32_t na0[2 * NDW], na1[2 * NDW], na2[2 * NDW], nxp[2 * NDW];
+};
+
+// one input row -> one output row (valid once 5 rows went in)
+template <int NDW, bool STORE>
+__device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, bool emit, bool active,
+                                       bool first_lane, bool last_lane, uint32_t *lh,
+                                       uint32_t *__restrict__ po)
+{
+    constexpr int NP = 2 * NDW;
+    // ---- pos / neg planes as u16 pairs (AnalyzerUnit.cpp:351-352) -----------------------------
+    uint32_t Xp[NP], Xn[NP];
+#pragma unroll
+    for (int d = 0; d < NDW; d++) {
+        uint32_t c0 = widen_lo(in.c[d]), c1 = widen_hi(in.c[d]);
+        uint32_t r0 = widen_lo(in.r[d]), r1 = widen_hi(in.r[d]);
+        uint32_t s0 = widen_lo(in.s[d]), s1 = widen_hi(in.s[d]);
+        Xp[2 * d] = pk_subsat(pk_subsat(c0, r0), s0);
+        Xn[2 * d] = pk_subsat(pk_subsat(r0, c0), s0);
+        Xp[2 * d + 1] = pk_subsat(pk_subsat(c1, r1), s1);
+        Xn[2 * d + 1] = pk_subsat(pk_subsat(r1, c1), s1);
+    }
+
+    // ---- horizontal 1-4-6-4-1 (+8 rounding share per row; AnalyzerUnit.cpp:359-360) -----------
+    // left pair (p[-2],p[-1]) and right pair (p[n],p[n+1]): neighbour lanes, reflect-101 at the edges
+    uint32_t reflLp = __builtin_amdgcn_perm(Xp[0], Xp[1], 0x07060100u); // (X1.lo, X0.hi) = (p2,p1)
+    uint32_t reflLn = __builtin_amdgcn_perm(Xn[0], Xn[1], 0x07060100u);
+    uint32_t reflRp = __builtin_amdgcn_perm(Xp[NP - 2], Xp[NP - 1], 0x07060100u); // (p[n-2],p[n-3])
+    uint32_t reflRn = __builtin_amdgcn_perm(Xn[NP - 2], Xn[NP - 1], 0x07060100u);
+    uint32_t Lp = __builtin_amdgcn_update_dpp(0u, Xp[NP - 1], DPP_WAVE_SHR1, 0xf, 0xf, false);
+    uint32_t Ln = __builtin_amdgcn_update_dpp(0u, Xn[NP - 1], DPP_WAVE_SHR1, 0xf, 0xf, false);
+    uint32_t Rp = __builtin_amdgcn_update_dpp(0u, Xp[0], DPP_WAVE_SHL1, 0xf, 0xf, false);
+    uint32_t Rn = __builtin_amdgcn_update_dpp(0u, Xn[0], DPP_WAVE_SHL1, 0xf, 0xf, false);
+    Lp = first_lane ? reflLp : Lp;
+    Ln = first_lane ? reflLn : Ln;
+    Rp = last_lane ? reflRp : Rp;
+    Rn = last_lane ? reflRn : Rn;
+
+    uint32_t Hp[NP], Hn[NP];
+    {
+        uint32_t am1p = __builtin_amdgcn_alignbit(Xp[0], Lp, 16); // (p[-1], p[0])
+        uint32_t am1n = __builtin_amdgcn_alignbit(Xn[0], Ln, 16);
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            uint32_t xm1p = j ? Xp[j - 1] : Lp, xp1p = j + 1 < NP ? Xp[j + 1] : Rp;
+            uint32_t xm1n = j ? Xn[j - 1] : Ln, xp1n = j + 1 < NP ? Xn[j + 1] : Rn;
+            uint32_t ap1p = __builtin_amdgcn_alignbit(xp1p, Xp[j], 16); // (p[2j+1], p[2j+2])
+            uint32_t ap1n = __builtin_amdgcn_alignbit(xp1n, Xn[j], 16);
+            uint32_t sp = am1p + ap1p, sn = am1n + ap1n;
+            uint32_t tp = xm1p + xp1p + 0x00080008u, tn = xm1n + xp1n + 0x00080008u;
+            tp = (sp << 2) + tp;
+            tn = (sn << 2) + tn;
+            Hp[j] = __umul24(Xp[j], 6u) + tp; // X <= 0x00ff00ff fits 24 bits
+            Hn[j] = __umul24(Xn[j], 6u) + tn;
+            am1p = ap1p;
+            am1n = ap1n;
+        }
+    }
+
+    // ---- vertical 1-4-6-4-1, (S+128)>>8, absdiff (AnalyzerUnit.cpp:370) -----------------------
+    uint32_t Dp[NP];
+    uint32_t any = 0;
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        uint32_t vp = A.pa0[j] + Hp[j];
+        uint32_t vn = A.na0[j] + Hn[j];
+        A.pa0[j] = (Hp[j] << 2) + A.pa1[j];
+        A.na0[j] = (Hn[j] << 2) + A.na1[j];
+        A.pa1[j] = pk_mad6(Hp[j], A.pa2[j]);
+        A.na1[j] = pk_mad6(Hn[j], A.na2[j]);
+        A.pa2[j] = (Hp[j] << 2) + A.pxp[j];
+        A.na2[j] = (Hn[j] << 2) + A.nxp[j];
+        A.pxp[j] = Hp[j];
+        A.nxp[j] = Hn[j];
+        uint32_t rp = __builtin_amdgcn_perm(0u, vp, 0x0c030c01u); // byte1, byte3 of the u16 lanes
+        uint32_t rn = __builtin_amdgcn_perm(0u, vn, 0x0c030c01u);
+        Dp[j] = pk_absdiff(rp, rn);
+        any |= Dp[j];
+    }
+
+    if (emit) {
+        if (any && active) { // rare: D is zero for almost every pixel
+#pragma unroll
+            for (int j = 0; j < NP; j++) {
+                uint32_t lo = Dp[j] & 0xffffu, hi = Dp[j] >> 16;
+                if (lo)
+                    atomicAdd(&lh[lo], 1u);
+                if (hi)
+                    atomicAdd(&lh[hi], 1u);
+            }
+        }
+        if (STORE && active) {
+#pragma unroll
+            for (int d = 0; d < NDW; d++)
+                po[d] = __builtin_amdgcn_perm(Dp[2 * d + 1], Dp[2 * d], 0x06040200u);
+        }
+    }
+}
+
+template <int NDW, bool STORE>
+__global__ __launch_bounds__(64) void k2_rows(const uint8_t *__restrict__ frames,
+                                              const uint8_t *__restrict__ sigma6,
+                                              const abub_job *__restrict__ jobs, int W, int H,
+                                              int rows_per_chunk, int nchunks,
+                                              uint32_t *__restrict__ hist, uint8_t *__restrict__ diff)
+{
+    constexpr int NP = 2 * NDW; // u16-pair registers per plane per lane
+    __shared__ uint32_t lh[256];
+
+    const int lane = threadIdx.x;
+    const int unit = blockIdx.x;
+    const int job = unit / nchunks;
+    const int chunk = unit - job * nchunks; // chunk fastest: unit % 8 == chunk % 8 when nchunks % 8 == 0
+    const abub_job jb = jobs[job];
+    const size_t P = (size_t)W * H;
+    const uint8_t *cur = frames + (size_t)jb.cur * P;
+    const uint8_t *ref = frames + (size_t)jb.ref * P;
+    const uint8_t *sg = sigma6 + (size_t)jb.model * P;
+    const int nl = W / (4 * NDW);
+    const bool active = lane < nl;
+    const bool first_lane = lane == 0;
+    const bool last_lane = lane == nl - 1;
+    const int xoff = lane * 4 * NDW;
+
+    const int y0 = chunk * rows_per_chunk;
+    int y1 = y0 + rows_per_chunk;
+    if (y1 > H)
+        y1 = H;
+    const int T = y1 - y0 + 4; // input rows y0-2 .. y1+1 (reflected)
+
+    lh[lane] = 0;
+    lh[lane + 64] = 0;
+    lh[lane + 128] = 0;
+    lh[lane + 192] = 0;
+    __syncthreads();
+
+    K2Acc<NDW> A;
+#pragma unroll
+    for (int j = 0; j < NP; j++)
+        A.pa0[j] = A.pa1[j] = A.pa2[j] = A.pxp[j] = A.na0[j] = A.na1[j] = A.na2[j] = A.nxp[j] = 0;
+
+    uint8_t *dbase = STORE ? diff + (size_t)jb.out * P + xoff : nullptr;
+
+    // two row buffers, manually unrolled by two so that neither the prefetch buffers nor the
+    // accumulators need register moves at the loop back-edge
+    RowIn<NDW> ra, rb;
+    k2_load_row<NDW>(ra, cur, ref, sg, reflect101(y0 - 2, H), W, xoff, active);
+    for (int t = 0; t < T; t += 2) {
+        {
+            int tn = t + 1 < T ? t + 1 : t;
+            k2_load_row<NDW>(rb, cur, ref, sg, reflect101(y0 - 2 + tn, H), W, xoff, active);
+        }
+        {
+            int y = y0 + t - 4;
+            k2_row<NDW, STORE>(ra, A, t >= 4, active, first_lane, last_lane, lh,
+                               reinterpret_cast<uint32_t *>(dbase + (ptrdiff_t)y * W));
+        }
+        if (t + 1 < T) {
+            int tn = t + 2 < T ? t + 2 : t + 1;
+            k2_load_row<NDW>(ra, cur, ref, sg, reflect101(y0 - 2 + tn, H), W, xoff, active);
+            int y = y0 + t + 1 - 4;
+            k2_row<NDW, STORE>(rb, A, t + 1 >= 4, active, first_lane, last_lane, lh,
+                               reinterpret_cast<uint32_t *>(dbase + (ptrdiff_t)y * W));
+        }
+    }
+
+    __syncthreads();
+    uint32_t *gh = hist + (size_t)jb.out * 256;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t v = lh[lane + 64 * k];
+        if (v && (lane + 64 * k))
+            atomicAdd(&gh[lane + 64 * k], v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 generic: any W,H and the ROI overload.  256-thread workgroup, 32x8 output tile, LDS tile of
+// packed (pos | neg<<16) with a 2-pixel halo; borders reflect inside the ROI.
+// ------------------------------------------------------------------------------------------------
+#define G_TW 32
+#define G_TH 8
+__global__ __launch_bounds__(256) void k2_generic(const uint8_t *__restrict__ frames,
+                                                  const uint8_t *__restrict__ sigma6,
+                                                  const abub_job *__restrict__ jobs,
+                                                  abub_job single, int use_single, int W, int H,
+                                                  int rx, int ry, int rw, int rh,
+                                                  uint32_t *__restrict__ hist,
+                                                  uint8_t *__restrict__ diff)
+{
+    __shared__ uint32_t tile[(G_TH + 4) * (G_TW + 4)];
+    __shared__ uint32_t lh[256];
+    const abub_job jb = use_single ? single : jobs[blockIdx.z];
+    const size_t P = (size_t)W * H;
+    const uint8_t *cur = frames + (size_t)jb.cur * P;
+    const uint8_t *ref = frames + (size_t)jb.ref * P;
+    const uint8_t *sg = sigma6 + (size_t)jb.model * P;
+    const int tid = threadIdx.x;
+    lh[tid] = 0;
+    const int tx0 = blockIdx.x * G_TW, ty0 = blockIdx.y * G_TH; // in ROI coordinates
+    for (int i = tid; i < (G_TH + 4) * (G_TW + 4); i += 256) {
+        int ly = i / (G_TW + 4), lx = i - ly * (G_TW + 4);
+        int x = reflect101(tx0 + lx - 2, rw) + rx;
+        int y = reflect101(ty0 + ly - 2, rh) + ry;
+        size_t o = (size_t)y * W + x;
+        int c = cur[o], r = ref[o], s6 = sg[o];
+        int pos = c - r;
+        pos = pos < 0 ? 0 : pos;
+        pos -= s6;
+        pos = pos < 0 ? 0 : pos;
+        int neg = r - c;
+        neg = neg < 0 ? 0 : neg;
+        neg -= s6;
+        neg = neg < 0 ? 0 : neg;
+        tile[i] = (uint32_t)pos | ((uint32_t)neg << 16);
+    }
+    __syncthreads();
+    const int lx = tid % G_TW, ly = tid / G_TW;
+    const int x = tx0 + lx, y = ty0 + ly;
+    if (x < rw && y < rh) {
+        const uint32_t w[5] = {1, 4, 6, 4, 1};
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            uint32_t rowacc = 0;
+#pragma unroll
+            for (int j = 0; j < 5; j++)
+                rowacc += w[j] * tile[(ly + i) * (G_TW + 4) + lx + j];
+            acc += w[i] * rowacc;
+        }
+        acc += 0x00800080u;
+        int a = (acc >> 8) & 0xff, b = acc >> 24;
+        int d = a > b ? a - b : b - a;
+        if (diff)
+            diff[(size_t)jb.out * P + (size_t)(y + ry) * W + (x + rx)] = (uint8_t)d;
+        if (d)
+            atomicAdd(&lh[d], 1u);
+    }
+    __syncthreads();
+    uint32_t v = lh[tid];
+    if (v && tid)
+        atomicAdd(&hist[(size_t)jb.out * 256 + tid], v);
+}
+
+static int pick_ndw(int W)
+{
+    if (W < 4 || (W & 3))
+        return 0;
+    int nd = W / 4;
+    for (int ndw = 1; ndw <= 8; ndw++)
+        if (nd % ndw == 0 && nd / ndw <= 64)
+            return ndw;
+    return 0;
+}
+
+template <int NDW>
+static void launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
+                           int njobs, int W, int H, int R, int nchunks, uint32_t *hist, uint8_t *diff,
+                           hipStream_t st)
+{
+    dim3 grid((unsigned)njobs * nchunks), block(64);
+    if (diff)
+        hipLaunchKernelGGL((k2_rows<NDW, true>), grid, block, 0, st, frames, sigma6, jobs, W, H, R,
+                           nchunks, hist, diff);
+    else
+        hipLaunchKernelGGL((k2_rows<NDW, false>), grid, block, 0, st, frames, sigma6, jobs, W, H, R,
+                           nchunks, hist, diff);
+}
+
+extern "C" int abub_diff_hist_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
+                                  int njobs, int W, int H, uint32_t *hist, uint8_t *diff,
+                                  int rows_per_chunk, void *stream)
+{
+    if (!frames || !sigma6 || !jobs || !hist || W <= 0 || H <= 0 || njobs < 0 || rows_per_chunk < 0)
+        return set_err(ABUB_E_INVALID, "abub_diff_hist_dev: bad arguments");
+    if (njobs == 0)
+        return ABUB_OK;
+    hipStream_t st = (hipStream_t)stream;
+    // hist slots are jb.out-indexed; the caller guarantees out < nslots == njobs for stack batches.
+    // We zero and finalise exactly njobs consecutive slots starting at 0 (documented contract).
+    HIPCHK(hipMemsetAsync(hist, 0, (size_t)njobs * 256 * sizeof(uint32_t), st));
+    int ndw = pick_ndw(W);
+    if (ndw) {
+        int R = rows_per_chunk;
+        if (R == 0) {
+            // many jobs: 8 chunks per frame (<= ~3% vertical halo re-reads, chunk id == XCD id);
+            // few jobs: short chunks so that a single frame still spreads over the chip
+            if (njobs >= 64)
+                R = (H + 7) / 8;
+            else if (njobs >= 8)
+                R = (H + 31) / 32;
+            else
+                R = 16;
+            if (R < 8)
+                R = 8;
+        }
+        int nchunks = (H + R - 1) / R;
+        switch (ndw) {
+        case 1: launch_k2_rows<1>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
+        case 2: launch_k2_rows<2>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
+        case 3: launch_k2_rows<3>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
+        case 4: launch_k2_rows<4>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
+        case 5: launch_k2_rows<5>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
+        case 6: launch_k2_rows<6>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
+        case 7: launch_k2_rows<7>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
+        default: launch_k2_rows<8>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
+        }
+    } else {
+        abub_job dummy = {0, 0, 0, 0};
+        dim3 grid((W + G_TW - 1) / G_TW, (H + G_TH - 1) / G_TH, njobs), block(256);
+        if (grid.z > 65535)
+            return set_err(ABUB_E_INVALID, "abub_diff_hist_dev: too many jobs for the generic kernel");
+        hipLaunchKernelGGL(k2_generic, grid, block, 0, st, frames, sigma6, jobs, dummy, 0, W, H, 0, 0,
+                           W, H, hist, diff);
+    }
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_hist_bin0, dim3(njobs), dim3(64), 0, st, hist, (uint32_t)((size_t)W * H));
+    HIPCHK(hipGetLastError());
+    return ABUB_OK;
+}
+
+extern "C" int abub_diff_roi_dev(const uint8_t *cur, const uint8_t *ref, const uint8_t *sigma6, int W,
+                                 int H, int rx, int ry, int rw, int rh, uint8_t *diff, uint32_t *hist,
+                                 void *stream)
+{
+    if (!cur || !ref || !sigma6 || !diff || !hist || W <= 0 || H <= 0 || rx < 0 || ry < 0 ||
+        rw < 0 || rh < 0 || rx + rw > W || ry + rh > H)
+        return set_err(ABUB_E_INVALID, "abub_diff_roi_dev: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    size_t P = (size_t)W * H;
+    HIPCHK(hipMemsetAsync(diff, 0, P, st)); // cv::Mat::zeros, AnalyzerUnit.cpp:349
+    HIPCHK(hipMemsetAsync(hist, 0, 256 * sizeof(uint32_t), st));
+    if (rw > 0 && rh > 0) {
+        // cur/ref/sigma6 are separate allocations: express them as frame offsets from `cur`... the
+        // generic kernel indexes frames by element count, so pass the three bases through pointer
+        // differences only when they share a slab.  Simplest exact way: one job with index 0 and
+        // dedicated base pointers.
+        abub_job jb = {0, 0, 0, 0};
+        dim3 grid((rw + G_TW - 1) / G_TW, (rh + G_TH - 1) / G_TH, 1), block(256);
+        // ref is addressed relative to cur: only valid if both lie in one slab at a multiple of P.
+        ptrdiff_t dref = ref - cur;
+        if (dref % (ptrdiff_t)P != 0 || dref < 0)
+            return set_err(ABUB_E_INVALID, "abub_diff_roi_dev: ref must follow cur in the same slab at a multiple of W*H");
+        jb.ref = (uint32_t)(dref / (ptrdiff_t)P);
+        hipLaunchKernelGGL(k2_generic, grid, block, 0, st, cur, sigma6, (const abub_job *)nullptr, jb, 1,
+                           W, H, rx, ry, rw, rh, hist, diff);
+        HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_hist_bin0, dim3(1), dim3(64), 0, st, hist, (uint32_t)P);
+    HIPCHK(hipGetLastError());
+    return ABUB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: float32 Welford, exactly the reference recurrence (Trainer.cpp:180-196); this TU is compiled
+// with -ffp-contract=off, and hipcc's default correctly-rounded fp32 divide / sqrt stays on.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k1_welford(const uint8_t *__restrict__ frames,
+                                                  const uint32_t *__restrict__ idx, int N, size_t P,
+                                                  uint8_t *__restrict__ mu, uint8_t *__restrict__ sigma)
+{
+    size_t px = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (px >= P)
+        return;
+    float mean = 0.f, m2 = 0.f;
+    for (int k = 0; k < N; k++) {
+        size_t f = idx ? idx[k] : (uint32_t)k;
+        float x = (float)frames[f * P + px];
+        float delta = x - mean;
+        mean = mean + delta / (float)(k + 1);
+        m2 = m2 + delta * (x - mean);
+    }
+    float var = m2 / (float)(N - 1);
+    float sd = sqrtf(var);
+    int isd = (sd != sd) ? 0 : (int)sd;
+    sigma[px] = (uint8_t)isd;
+    mu[px] = (uint8_t)(int)mean;
+}
+
+// 4 pixels per thread (dword loads) when P % 4 == 0
+__global__ __launch_bounds__(256) void k1_welford4(const uint8_t *__restrict__ frames,
+                                                   const uint32_t *__restrict__ idx, int N, size_t P,
+                                                   uint8_t *__restrict__ mu,
+                                                   uint8_t *__restrict__ sigma)
+{
+    size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // dword index
+    if (q * 4 >= P)
+        return;
+    float mean[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < N; k++) {
+        size_t f = idx ? idx[k] : (uint32_t)k;
+        uint32_t w = reinterpret_cast<const uint32_t *>(frames + f * P)[q];
+        float kk = (float)(k + 1);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            float x = (float)((w >> (8 * b)) & 0xffu);
+            float delta = x - mean[b];
+            mean[b] = mean[b] + delta / kk;
+            m2[b] = m2[b] + delta * (x - mean[b]);
+        }
+    }
+    uint32_t om = 0, os = 0;
+    float nm1 = (float)(N - 1);
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        float sd = sqrtf(m2[b] / nm1);
+        int isd = (sd != sd) ? 0 : (int)sd;
+        os |= (uint32_t)(isd & 0xff) << (8 * b);
+        om |= (uint32_t)((int)mean[b] & 0xff) << (8 * b);
+    }
+    reinterpret_cast<uint32_t *>(mu)[q] = om;
+    reinterpret_cast<uint32_t *>(sigma)[q] = os;
+}
+
+extern "C" int abub_train_dev(const uint8_t *frames, const uint32_t *idx, int N, int W, int H,
+                              uint8_t *mu, uint8_t *sigma, void *stream)
+{
+    if (!frames || !mu || !sigma || N <= 0 || W <= 0 || H <= 0)
+        return set_err(ABUB_E_INVALID, "abub_train_dev: bad arguments");
+    size_t P = (size_t)W * H;
+    hipStream_t st = (hipStream_t)stream;
+    if ((P & 3) == 0) {
+        size_t nq = P / 4;
+        hipLaunchKernelGGL(k1_welford4, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, frames,
+                           idx, N, P, mu, sigma);
+    } else {
+        hipLaunchKernelGGL(k1_welford, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, frames, idx,
+                           N, P, mu, sigma);
+    }
+    HIPCHK(hipGetLastError());
+    return ABUB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1b: 256-bin histogram of sat(f1 - f0), grid (blocks_per_pair, npairs)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k1b_pair_hist(const uint8_t *__restrict__ frames,
+                                                     const abub_job *__restrict__ pairs, size_t P,
+                                                     uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t lh[256];
+    const abub_job jb = pairs[blockIdx.y];
+    const uint8_t *f1 = frames + (size_t)jb.cur * P;
+    const uint8_t *f0 = frames + (size_t)jb.ref * P;
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
+        int d = (int)f1[i] - (int)f0[i];
+        if (d > 0)
+            atomicAdd(&lh[d], 1u);
+    }
+    __syncthreads();
+    uint32_t v = lh[threadIdx.x];
+    if (v && threadIdx.x)
+        atomicAdd(&hist[(size_t)jb.out * 256 + threadIdx.x], v);
+}
+
+extern "C" int abub_pair_hist_dev(const uint8_t *frames, const abub_job *pairs, int npairs, int W,
+                                  int H, uint32_t *hist, void *stream)
+{
+    if (!frames || !pairs || !hist || npairs < 0 || W <= 0 || H <= 0)
+        return set_err(ABUB_E_INVALID, "abub_pair_hist_dev: bad arguments");
+    if (npairs == 0)
+        return ABUB_OK;
+    if (npairs > 65535)
+        return set_err(ABUB_E_INVALID, "abub_pair_hist_dev: npairs > 65535");
+    hipStream_t st = (hipStream_t)stream;
+    size_t P = (size_t)W * H;
+    HIPCHK(hipMemsetAsync(hist, 0, (size_t)npairs * 256 * sizeof(uint32_t), st));
+    int bx = (int)((P + 256 * 16 - 1) / (256 * 16));
+    if (bx < 1)
+        bx = 1;
+    hipLaunchKernelGGL(k1b_pair_hist, dim3(bx, npairs), dim3(256), 0, st, frames, pairs, P, hist);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_hist_bin0, dim3(npairs), dim3(64), 0, st, hist, (uint32_t)P);
+    HIPCHK(hipGetLastError());
+    return ABUB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 generic: O = max(0,|f-mu| - 6 sigma), 3x3 box (S+4)/9, histogram.  32x8 tile + 1-pixel halo.
+// (S+4)/9 == ((S+4)*7282)>>16 for every reachable S (0..2295): checked exhaustively in tests.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k3_generic(const uint8_t *__restrict__ frames,
+                                                  const uint8_t *__restrict__ mu,
+                                                  const uint8_t *__restrict__ sigma6,
+                                                  const abub_job *__restrict__ jobs, int W, int H,
+                                                  uint32_t *__restrict__ hist, uint8_t *__restrict__ img)
+{
+    __shared__ uint16_t tile[(G_TH + 2) * (G_TW + 2)];
+    __shared__ uint32_t lh[256];
+    const abub_job jb = jobs[blockIdx.z];
+    const size_t P = (size_t)W * H;
+    const uint8_t *f = frames + (size_t)jb.cur * P;
+    const uint8_t *m = mu + (size_t)jb.model * P;
+    const uint8_t *sg = sigma6 + (size_t)jb.model * P;
+    const int tid = threadIdx.x;
+    lh[tid] = 0;
+    const int tx0 = blockIdx.x * G_TW, ty0 = blockIdx.y * G_TH;
+    for (int i = tid; i < (G_TH + 2) * (G_TW + 2); i += 256) {
+        int ly = i / (G_TW + 2), lx = i - ly * (G_TW + 2);
+        int x = reflect101(tx0 + lx - 1, W);
+        int y = reflect101(ty0 + ly - 1, H);
+        size_t o = (size_t)y * W + x;
+        int a = (int)f[o] - (int)m[o];
+        a = a < 0 ? -a : a;
+        a -= (int)sg[o];
+        tile[i] = (uint16_t)(a < 0 ? 0 : a);
+    }
+    __syncthreads();
+    const int lx = tid % G_TW, ly = tid / G_TW;
+    const int x = tx0 + lx, y = ty0 + ly;
+    if (x < W && y < H) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                s += tile[(ly + i) * (G_TW + 2) + lx + j];
+        uint32_t v = (s + 4) / 9;
+        if (img)
+            img[(size_t)jb.out * P + (size_t)y * W + x] = (uint8_t)v;
+        if (v)
+            atomicAdd(&lh[v], 1u);
+    }
+    __syncthreads();
+    uint32_t v = lh[tid];
+    if (v && tid)
+        atomicAdd(&hist[(size_t)jb.out * 256 + tid], v);
+}
+
+extern "C" int abub_posttrig_dev(const uint8_t *frames, const uint8_t *mu, const uint8_t *sigma6,
+                                 const abub_job *jobs, int njobs, int W, int H, uint32_t *hist,
+                                 uint8_t *img, void *stream)
+{
+    if (!frames || !mu || !sigma6 || !jobs || !hist || W <= 0 || H <= 0 || njobs < 0)
+        return set_err(ABUB_E_INVALID, "abub_posttrig_dev: bad arguments");
+    if (njobs == 0)
+        return ABUB_OK;
+    if (njobs > 65535)
+        return set_err(ABUB_E_INVALID, "abub_posttrig_dev: njobs > 65535");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(hist, 0, (size_t)njobs * 256 * sizeof(uint32_t), st));
+    dim3 grid((W + G_TW - 1) / G_TW, (H + G_TH - 1) / G_TH, njobs), block(256);
+    hipLaunchKernelGGL(k3_generic, grid, block, 0, st, frames, mu, sigma6, jobs, W, H, hist, img);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_hist_bin0, dim3(njobs), dim3(64), 0, st, hist, (uint32_t)((size_t)W * H));
+    HIPCHK(hipGetLastError());
+    return ABUB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: binarize + foreground compaction.  grid (blocks, nimg); 16 pixels per thread per step when
+// the image size allows it.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k4_compact(const uint8_t *__restrict__ img, size_t P,
+                                                  const int32_t *__restrict__ thr,
+                                                  uint32_t *__restrict__ idx, int cap,
+                                                  uint32_t *__restrict__ count)
+{
+    const int k = blockIdx.y;
+    const uint8_t *im = img + (size_t)k * P;
+    const int t = thr[k];
+    uint32_t *cnt = count + k;
+    uint32_t *out = idx + (size_t)k * cap;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    if ((P & 15) == 0) {
+        size_t nv = P / 16;
+        for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nv; q += stride) {
+            uint4 w = reinterpret_cast<const uint4 *>(im)[q];
+            uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+            // v > t  for any byte?  quick reject: all bytes <= t
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                if (ww[d] == 0)
+                    continue;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    int v = (ww[d] >> (8 * b)) & 0xff;
+                    if (v > t) {
+                        uint32_t pos = atomicAdd(cnt, 1u);
+                        if (pos < (uint32_t)cap)
+                            out[pos] = (uint32_t)(q * 16 + d * 4 + b);
+                    }
+                }
+            }
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
+            if ((int)im[i] > t) {
+                uint32_t pos = atomicAdd(cnt, 1u);
+                if (pos < (uint32_t)cap)
+                    out[pos] = (uint32_t)i;
+            }
+        }
+    }
+}
+
+extern "C" int abub_fg_compact_dev(const uint8_t *img, int nimg, int W, int H, const int32_t *thr,
+                                   uint32_t *idx, int cap, uint32_t *count, void *stream)
+{
+    if (!img || !thr || !idx || !count || nimg < 0 || W <= 0 || H <= 0 || cap <= 0)
+        return set_err(ABUB_E_INVALID, "abub_fg_compact_dev: bad arguments");
+    if (nimg == 0)
+        return ABUB_OK;
+    if (nimg > 65535)
+        return set_err(ABUB_E_INVALID, "abub_fg_compact_dev: nimg > 65535");
+    hipStream_t st = (hipStream_t)stream;
+    size_t P = (size_t)W * H;
+    HIPCHK(hipMemsetAsync(count, 0, (size_t)nimg * sizeof(uint32_t), st));
+    int bx = (int)((P / 16 + 255) / 256);
+    if (bx < 1)
+        bx = 1;
+    if (bx > 512)
+        bx = 512;
+    hipLaunchKernelGGL(k4_compact, dim3(bx, nimg), dim3(256), 0, st, img, P, thr, idx, cap, count);
+    HIPCHK(hipGetLastError());
+    return ABUB_OK;
+}

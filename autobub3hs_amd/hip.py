@@ -1,0 +1,109 @@
+"""Thin Python mirror of the stateless device-pointer launchers (include/abub_hip.h layer A).
+
+torch is plumbing only: it owns the HBM allocations and the stream the kernels are launched on.
+"""
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.AbubError("device-pointer launcher called with a CPU tensor (no CPU fallback)")
+        if t is not None and not t.is_contiguous():
+            raise _lib.AbubError("tensor must be contiguous")
+
+
+def sigma6(sigma):
+    _need_cuda(sigma)
+    out = torch.empty_like(sigma)
+    _lib.check(_lib.lib().abub_sigma6_dev(_ptr(sigma), _ptr(out), sigma.numel(), _stream()), "abub_sigma6_dev")
+    return out
+
+
+def stack_jobs(nstacks, F, first, count, ref_offset, nmodels, device):
+    jobs = torch.empty((nstacks * count, 4), dtype=torch.int32, device=device)
+    _lib.check(_lib.lib().abub_fill_stack_jobs_dev(_ptr(jobs), nstacks, F, first, count, ref_offset,
+                                                   nmodels, _stream()), "abub_fill_stack_jobs_dev")
+    return jobs
+
+
+def make_jobs(rows, device):
+    """rows: iterable of (cur, ref, model, out)."""
+    return torch.tensor(list(rows), dtype=torch.int64).to(torch.int32).reshape(-1, 4).to(device)
+
+
+def diff_hist(frames, sigma6_, jobs, W, H, store=False, rows_per_chunk=0, hist=None, diff=None):
+    """K2. frames: u8 [..,H,W]; sigma6_: u8 [nmodels,H,W]; jobs: int32 [n,4] -> (hist [n,256] i32, diff|None)."""
+    _need_cuda(frames, sigma6_, jobs)
+    n = jobs.shape[0]
+    if hist is None:
+        hist = torch.empty((n, 256), dtype=torch.int32, device=frames.device)
+    if store and diff is None:
+        diff = torch.empty((n, H, W), dtype=torch.uint8, device=frames.device)
+    _lib.check(_lib.lib().abub_diff_hist_dev(_ptr(frames), _ptr(sigma6_), _ptr(jobs), n, W, H, _ptr(hist),
+                                             _ptr(diff) if store else None, rows_per_chunk, _stream()),
+               "abub_diff_hist_dev")
+    return hist, (diff if store else None)
+
+
+def diff_roi(slab, cur, ref, sigma6_, W, H, roi):
+    """ProcessFrame ROI overload on frames `cur`,`ref` (indices, ref >= cur... see header) of one slab."""
+    _need_cuda(slab, sigma6_)
+    rx, ry, rw, rh = roi
+    diff = torch.empty((H, W), dtype=torch.uint8, device=slab.device)
+    hist = torch.empty((256,), dtype=torch.int32, device=slab.device)
+    P = W * H
+    base = slab.data_ptr()
+    _lib.check(_lib.lib().abub_diff_roi_dev(base + cur * P, base + ref * P, _ptr(sigma6_), W, H, rx, ry, rw, rh,
+                                            _ptr(diff), _ptr(hist), _stream()), "abub_diff_roi_dev")
+    return diff, hist
+
+
+def train(frames, W, H, idx=None):
+    _need_cuda(frames, idx)
+    N = frames.shape[0] if idx is None else idx.numel()
+    mu = torch.empty((H, W), dtype=torch.uint8, device=frames.device)
+    sg = torch.empty((H, W), dtype=torch.uint8, device=frames.device)
+    _lib.check(_lib.lib().abub_train_dev(_ptr(frames), _ptr(idx), N, W, H, _ptr(mu), _ptr(sg), _stream()),
+               "abub_train_dev")
+    return mu, sg
+
+
+def pair_hist(frames, pairs, W, H):
+    _need_cuda(frames, pairs)
+    n = pairs.shape[0]
+    hist = torch.empty((n, 256), dtype=torch.int32, device=frames.device)
+    _lib.check(_lib.lib().abub_pair_hist_dev(_ptr(frames), _ptr(pairs), n, W, H, _ptr(hist), _stream()),
+               "abub_pair_hist_dev")
+    return hist
+
+
+def posttrig(frames, mu, sigma6_, jobs, W, H, store=True):
+    _need_cuda(frames, mu, sigma6_, jobs)
+    n = jobs.shape[0]
+    hist = torch.empty((n, 256), dtype=torch.int32, device=frames.device)
+    img = torch.empty((n, H, W), dtype=torch.uint8, device=frames.device) if store else None
+    _lib.check(_lib.lib().abub_posttrig_dev(_ptr(frames), _ptr(mu), _ptr(sigma6_), _ptr(jobs), n, W, H,
+                                            _ptr(hist), _ptr(img), _stream()), "abub_posttrig_dev")
+    return hist, img
+
+
+def fg_compact(img, thr, cap):
+    """img: u8 [n,H,W]; thr: int32 [n] -> (idx int32 [n,cap], count int32 [n])."""
+    _need_cuda(img, thr)
+    n, H, W = img.shape
+    idx = torch.empty((n, cap), dtype=torch.int32, device=img.device)
+    cnt = torch.empty((n,), dtype=torch.int32, device=img.device)
+    _lib.check(_lib.lib().abub_fg_compact_dev(_ptr(img), n, W, H, _ptr(thr), _ptr(idx), cap, _ptr(cnt),
+                                              _stream()), "abub_fg_compact_dev")
+    return idx, cnt

@@ -1,0 +1,149 @@
+/*
+ * abub_hip.h -- C ABI of the MI355X (gfx950) bubble-detection hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types, no exceptions.
+ * The reference (picoexperiment/AutoBub3hs) is a single C++ process with no FFI of its own; these
+ * entry points are what its AnalyzerUnit / L3Localizer / Trainer methods would bind for the
+ * per-pixel work they delegate to OpenCV today.  Each entry cites the reference code it replaces
+ * (paths relative to the reference root).  INTEGRATION.md shows the call sites a maintainer edits.
+ *
+ * Two layers:
+ *   (A) abub_*_dev  : stateless launchers on DEVICE pointers + a hipStream_t (passed as void*).
+ *                     Used by bench.py / tests with torch-owned HBM and by layer (B).
+ *   (B) abub_ctx_*  : a per-host-thread context that owns HBM slabs (frame stack, model, scratch)
+ *                     and moves HOST buffers in and out.  One ctx per host thread (the reference runs
+ *                     one analyzer per OpenMP thread, AutoBubStart3.cpp:342); contexts are independent
+ *                     and re-entrant.
+ *
+ * All functions return 0 on success or a negative code (ABUB_E_*); abub_last_error() gives text.
+ * Images are single-channel u8, row-major, pitch == W.
+ */
+#ifndef ABUB_HIP_H
+#define ABUB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ABUB_OK 0
+#define ABUB_E_INVALID (-1)   /* bad argument (shape, null pointer, range) */
+#define ABUB_E_HIP (-2)       /* HIP runtime error (see abub_last_error) */
+#define ABUB_E_NODEVICE (-3)  /* no usable gfx950 device */
+#define ABUB_E_OVERFLOW (-4)  /* caller-provided capacity too small (count still reported) */
+
+/* A unit of K2/K3 work: indices (in frames) into a frame slab and a model slab. */
+typedef struct {
+    uint32_t cur;   /* frame index of the current frame in `frames`            */
+    uint32_t ref;   /* frame index of the reference frame in `frames` (K2)      */
+    uint32_t model; /* index into the [nmodels][H][W] sigma6 / mu slabs         */
+    uint32_t out;   /* output slot: hist[out][256] and, if stored, img[out][H][W] */
+} abub_job;
+
+const char *abub_last_error(void);
+int abub_device_count(void);
+/* name/CU count/HBM bytes of a device, e.g. for bench.py's config block */
+int abub_device_info(int device, char *name, int name_cap, int *cus, uint64_t *hbm_bytes);
+
+/* ------------------------------------------------------------------------------------------- */
+/* (A) stateless device-pointer launchers                                                      */
+/* ------------------------------------------------------------------------------------------- */
+
+/* sigma6[i] = min(6*sigma[i], 255): the saturated `6*TrainedSigmaImage` operand of
+ * AnalyzerUnit.cpp:351-352 and L3Localizer.cpp:782, computed once per model. n = bytes. */
+int abub_sigma6_dev(const uint8_t *sigma, uint8_t *sigma6, size_t n, void *stream);
+
+/* Fill jobs for regular stacks: `nstacks` stacks of F frames laid out [nstacks][F][H][W]; for stack s
+ * and i in [first, first+count): cur = s*F+i, ref = s*F+max(i-ref_offset,0), model = s % nmodels,
+ * out = s*count + (i-first).  (FindTriggerFrame's frame pairing, AnalyzerUnit.cpp:175-177,218,312-313.) */
+int abub_fill_stack_jobs_dev(abub_job *jobs, int nstacks, int F, int first, int count, int ref_offset,
+                             int nmodels, void *stream);
+
+/* K2: fused AnalyzerUnit::ProcessFrame (AnalyzerUnit.cpp:346-377: two saturating differences
+ * minus 6 sigma, 5x5 Gaussian of each, absdiff) + cv::calcHist 256 bins (AnalyzerUnit.cpp:456).
+ *   frames  : [..][H][W] u8 slab            sigma6 : [nmodels][H][W] from abub_sigma6_dev
+ *   jobs    : njobs entries (device)         hist   : [nslots][256] u32 (device), fully overwritten
+ *   diff    : NULL (trigger-only mode, 3*W*H algorithmic bytes/job) or [nslots][H][W] u8
+ *             (store mode, 4*W*H bytes/job)
+ *   rows_per_chunk: 0 = auto.  Fast register-rolling kernel when W%4==0 and W<=2048, generic
+ *   LDS-tile kernel otherwise (same results). */
+int abub_diff_hist_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs, int njobs,
+                       int W, int H, uint32_t *hist, uint8_t *diff, int rows_per_chunk, void *stream);
+
+/* Same on a sub-rectangle (ProcessFrame ROI overload, AnalyzerUnit.cpp:346: borders reflect at the
+ * ROI edge, zeros outside).  One job; always the generic kernel. */
+int abub_diff_roi_dev(const uint8_t *cur, const uint8_t *ref, const uint8_t *sigma6, int W, int H,
+                      int rx, int ry, int rw, int rh, uint8_t *diff, uint32_t *hist, void *stream);
+
+/* K1: Trainer::CalculateMeanSigmaImageVector (Trainer.cpp:144-216): float32 Welford over the
+ * N frames `idx[0..N)` (device array of frame indices, NULL = 0..N-1) of `frames`. */
+int abub_train_dev(const uint8_t *frames, const uint32_t *idx, int N, int W, int H, uint8_t *mu,
+                   uint8_t *sigma, void *stream);
+
+/* K1b: histogram (256 bins) of the saturating difference f1 - f0 for npairs frame pairs
+ * (Trainer.cpp:279 + the calcHist of :365); pairs[k] = {cur=f1, ref=f0, -, out}. */
+int abub_pair_hist_dev(const uint8_t *frames, const abub_job *pairs, int npairs, int W, int H,
+                       uint32_t *hist, void *stream);
+
+/* K3: fused L3Localizer::CalculatePostTriggerFrameParams pixel stage (L3Localizer.cpp:779-785:
+ * absdiff against mu, minus 6 sigma, 3x3 box blur) + 256-bin histogram (for the Otsu of :787).
+ * jobs[k] = {cur, -, model, out}; img = [nslots][H][W] (may be NULL: histogram only). */
+int abub_posttrig_dev(const uint8_t *frames, const uint8_t *mu, const uint8_t *sigma6,
+                      const abub_job *jobs, int njobs, int W, int H, uint32_t *hist, uint8_t *img,
+                      void *stream);
+
+/* K4: binarize (v > thr[k]) + stream-compaction of foreground pixel indices, for nimg images
+ * img[k] (the TOZERO + BINARY|OTSU mask of L3Localizer.cpp:252-254,786-787 with
+ * thr = max(loc_thres, otsu)).  idx: [nimg][cap] u32 raster indices (unordered); count: [nimg]
+ * (true counts, may exceed cap -> caller falls back to abub_fetch). */
+int abub_fg_compact_dev(const uint8_t *img, int nimg, int W, int H, const int32_t *thr,
+                        uint32_t *idx, int cap, uint32_t *count, void *stream);
+
+/* ------------------------------------------------------------------------------------------- */
+/* (B) context API (host buffers in/out)                                                       */
+/* ------------------------------------------------------------------------------------------- */
+
+typedef struct abub_ctx abub_ctx;
+
+/* One context per host thread; owns a frame slab for up to max_frames frames of W x H. */
+int abub_ctx_create(abub_ctx **out, int device, int W, int H, int max_frames);
+void abub_ctx_destroy(abub_ctx *ctx);
+
+/* Trainer::CalculateMeanSigmaImageVector on N host frames (Trainer.cpp:316); fills host mu/sigma.
+ * The frames go through the ctx slab in blocks, so N is not limited by max_frames. */
+int abub_ctx_train(abub_ctx *ctx, const uint8_t *const *frames, int N, uint8_t *mu_out,
+                   uint8_t *sigma_out);
+/* 256-bin histogram of sat(f1 - f0) (training entropy veto, Trainer.cpp:279-280). */
+int abub_ctx_pair_hist(abub_ctx *ctx, const uint8_t *f0, const uint8_t *f1, uint32_t hist[256]);
+
+/* Make (mu, sigma) the context's current model (AnalyzerUnit.cpp:27 deep-copies the Trainer per
+ * analyzer; here the model lives once in HBM). */
+int abub_ctx_set_model(abub_ctx *ctx, const uint8_t *mu, const uint8_t *sigma);
+
+/* Upload the frame stack of one (event, camera): F host frame pointers (Parser::GetImage results). */
+int abub_ctx_upload_stack(abub_ctx *ctx, const uint8_t *const *frames, int F);
+
+/* Histograms of D(frame[i]; frame[max(i-ref_offset,0)]) for i in [first, first+count):
+ * everything FindTriggerFrame needs (AnalyzerUnit.cpp:191-314).  hist_out: [count][256] host. */
+int abub_ctx_diff_hist_batch(abub_ctx *ctx, int ref_offset, int first, int count, uint32_t *hist_out);
+
+/* D(frame[i]; frame[ref]) materialised (L3Localizer.cpp:232); D_out/hist_out may be NULL.
+ * The image stays resident as the context's "current image" for abub_ctx_foreground. */
+int abub_ctx_diff_frame(abub_ctx *ctx, int i, int ref, uint8_t *D_out, uint32_t *hist_out);
+
+/* Post-trigger image of frame i (L3Localizer.cpp:779-785) + histogram; becomes the current image. */
+int abub_ctx_posttrig(abub_ctx *ctx, int i, uint8_t *O_out, uint32_t *hist_out);
+
+/* Foreground pixels (v > thr) of the current image as raster indices; *n = true count.
+ * Returns ABUB_E_OVERFLOW if *n > cap (idx_out then holds the first cap found). */
+int abub_ctx_foreground(abub_ctx *ctx, int thr, uint32_t *idx_out, int cap, int *n);
+
+/* Copy the current image to the host (debug write-out / overflow fallback). */
+int abub_ctx_fetch_image(abub_ctx *ctx, uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,189 @@
+"""GPU parity tests proper: every HIP kernel, called through the C-ABI (device-pointer layer), must
+match the CPU oracle bit for bit on the same seeded inputs."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from autobub3hs_amd import hip, synth  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def rnd_frames(rs, n, H, W, base=None, amp=12):
+    if base is None:
+        base = rs.randint(30, 200, (H, W))
+    fr = base[None] + rs.randint(-amp, amp + 1, (n, H, W))
+    return np.clip(fr, 0, 255).astype(np.uint8)
+
+
+def oracle_hists(oracle, frames, sigma, jobs):
+    Ds, hs = [], []
+    for (c, r, m, o) in jobs:
+        D = oracle.process_frame(frames[c], frames[r], sigma[m])
+        Ds.append(D)
+        hs.append(oracle.hist256(D))
+    return np.stack(Ds), np.stack(hs)
+
+
+K2_SHAPES = [
+    (64, 1280, 0), (50, 1680, 0), (37, 256, 8), (40, 512, 16), (33, 768, 0), (16, 1024, 8),
+    (9, 1536, 0), (21, 2048, 8), (64, 100, 16),      # fast path NDW = 5,7,1,2,3,4,6,8,1(25 lanes)
+    (37, 53, 0), (5, 5, 0), (12, 6, 0), (1, 16, 0), (2, 8, 0), (3, 4, 0),  # generic / degenerate
+]
+
+
+@pytest.mark.parametrize("H,W,R", K2_SHAPES)
+def test_k2_diff_hist_parity(oracle, H, W, R):
+    rs = np.random.RandomState(H * 10007 + W)
+    n = 6
+    frames = rnd_frames(rs, n, H, W)
+    sigma = rs.randint(0, 3, (2, H, W)).astype(np.uint8)
+    jobs = [(i, max(i - 2, 0), i % 2, k) for k, i in enumerate(range(1, n))]
+    Dref, href = oracle_hists(oracle, frames, sigma, jobs)
+    f_d = torch.from_numpy(frames).to(DEV)
+    s6 = hip.sigma6(torch.from_numpy(sigma).to(DEV))
+    assert np.array_equal(s6.cpu().numpy(), np.minimum(6 * sigma.astype(int), 255).astype(np.uint8))
+    j_d = hip.make_jobs(jobs, DEV)
+    for store in (True, False):
+        hist, diff = hip.diff_hist(f_d, s6, j_d, W, H, store=store, rows_per_chunk=R)
+        torch.cuda.synchronize()
+        assert np.array_equal(hist.cpu().numpy().astype(np.uint32), href), (H, W, store)
+        if store:
+            assert np.array_equal(diff.cpu().numpy(), Dref)
+
+
+def test_k2_extreme_values(oracle):
+    # saturation everywhere: 255 vs 0 with sigma 0 / large sigma, constant planes
+    H, W = 24, 1280
+    frames = np.zeros((3, H, W), np.uint8)
+    frames[1] = 255
+    frames[2, ::2, ::3] = 255
+    sigma = np.zeros((2, H, W), np.uint8)
+    sigma[1] = 50
+    jobs = [(1, 0, 0, 0), (0, 1, 0, 1), (2, 0, 0, 2), (2, 1, 0, 3), (1, 0, 1, 4), (2, 1, 1, 5)]
+    Dref, href = oracle_hists(oracle, frames, sigma, jobs)
+    f_d = torch.from_numpy(frames).to(DEV)
+    s6 = hip.sigma6(torch.from_numpy(sigma).to(DEV))
+    hist, diff = hip.diff_hist(f_d, s6, hip.make_jobs(jobs, DEV), W, H, store=True)
+    assert np.array_equal(diff.cpu().numpy(), Dref)
+    assert np.array_equal(hist.cpu().numpy().astype(np.uint32), href)
+
+
+def test_k2_stack_jobs_and_synthetic_event(oracle):
+    W, H, F = 1280, 96, 16
+    spec = synth.EventSpec(F, t0=9, bubbles=[(400, 40, 40), (900, 70, -40)])
+    fr = synth.render_event(W, H, spec, 5, 0)
+    tr = synth.training_pairs(W, H, 6, 0, F)
+    mu, sg = oracle.welford(tr)
+    f_d = torch.from_numpy(fr).to(DEV)
+    s6 = hip.sigma6(torch.from_numpy(sg[None]).to(DEV))
+    jobs = hip.stack_jobs(1, F, 1, F - 1, 2, 1, DEV)
+    jn = jobs.cpu().numpy()
+    assert [tuple(r) for r in jn] == [(i, max(i - 2, 0), 0, i - 1) for i in range(1, F)]
+    hist, _ = hip.diff_hist(f_d, s6, jobs, W, H)
+    _, href = oracle.bench_trigger_pass(fr, sg, 2, 1, F - 1, want_hists=True)
+    assert np.array_equal(hist.cpu().numpy().astype(np.uint32), href)
+    assert href[spec.t0 - 1, 1:].sum() > 0  # the bubble is visible in the genesis frame
+
+
+def test_k2_roi_parity(oracle):
+    H, W = 60, 72
+    rs = np.random.RandomState(3)
+    frames = rnd_frames(rs, 2, H, W, amp=30)
+    sigma = rs.randint(0, 3, (H, W)).astype(np.uint8)
+    f_d = torch.from_numpy(frames).to(DEV)
+    s6 = hip.sigma6(torch.from_numpy(sigma).to(DEV))
+    for roi in [(7, 11, 23, 17), (0, 0, W, H), (70, 58, 2, 2), (5, 5, 1, 9)]:
+        D, h = hip.diff_roi(f_d, 0, 1, s6, W, H, roi)
+        Dref = oracle.process_frame(frames[0], frames[1], sigma, roi=roi)
+        assert np.array_equal(D.cpu().numpy(), Dref), roi
+        assert np.array_equal(h.cpu().numpy().astype(np.uint32), oracle.hist256(Dref))
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 16, 32), (13, 9, 11), (40, 32, 64), (7, 5, 3), (1, 4, 8)])
+def test_k1_welford_parity(oracle, N, H, W):
+    rs = np.random.RandomState(N * 31 + W)
+    st = rs.randint(0, 256, (N, H, W)).astype(np.uint8)
+    if N == 40:
+        st = rnd_frames(rs, N, H, W, amp=3)  # realistic: small sigma, truncation boundaries
+    mu_r, sg_r = oracle.welford(st)
+    mu, sg = hip.train(torch.from_numpy(st).to(DEV), W, H)
+    assert np.array_equal(mu.cpu().numpy(), mu_r)
+    assert np.array_equal(sg.cpu().numpy(), sg_r)
+    # with an index list (training set = frames 0,1 of the good events only)
+    if N >= 4:
+        idx = np.array([0, 1, N - 2, N - 1], np.int32)
+        mu_r, sg_r = oracle.welford(st[idx])
+        mu, sg = hip.train(torch.from_numpy(st).to(DEV), W, H, idx=torch.from_numpy(idx).to(DEV))
+        assert np.array_equal(mu.cpu().numpy(), mu_r) and np.array_equal(sg.cpu().numpy(), sg_r)
+
+
+def test_k1b_pair_hist_parity(oracle):
+    H, W = 48, 80
+    rs = np.random.RandomState(5)
+    fr = rnd_frames(rs, 6, H, W, amp=40)
+    pairs = [(1, 0, 0, 0), (3, 2, 0, 1), (5, 4, 0, 2), (0, 0, 0, 3)]
+    h = hip.pair_hist(torch.from_numpy(fr).to(DEV), hip.make_jobs(pairs, DEV), W, H).cpu().numpy()
+    for (a, b, _, o) in pairs:
+        d = np.clip(fr[a].astype(int) - fr[b].astype(int), 0, 255).astype(np.uint8)
+        assert np.array_equal(h[o].astype(np.uint32), oracle.hist256(d))
+
+
+@pytest.mark.parametrize("H,W", [(40, 56), (3, 3), (17, 5), (64, 1280), (1, 7)])
+def test_k3_posttrig_parity(oracle, H, W):
+    rs = np.random.RandomState(H + W)
+    fr = rnd_frames(rs, 3, H, W, amp=25)
+    mu = rs.randint(0, 256, (2, H, W)).astype(np.uint8)
+    mu[0] = np.clip(fr[0].astype(int) + rs.randint(-2, 3, (H, W)), 0, 255)
+    sg = rs.randint(0, 3, (2, H, W)).astype(np.uint8)
+    jobs = [(0, 0, 0, 0), (1, 0, 1, 1), (2, 0, 0, 2)]
+    hist, img = hip.posttrig(torch.from_numpy(fr).to(DEV), torch.from_numpy(mu).to(DEV),
+                             hip.sigma6(torch.from_numpy(sg).to(DEV)), hip.make_jobs(jobs, DEV), W, H)
+    for (c, _, m, o) in jobs:
+        O = oracle.posttrig_frame(fr[c], mu[m], sg[m])
+        assert np.array_equal(img[o].cpu().numpy(), O)
+        assert np.array_equal(hist[o].cpu().numpy().astype(np.uint32), oracle.hist256(O))
+
+
+def test_k4_foreground_compaction(oracle):
+    H, W = 64, 80
+    rs = np.random.RandomState(9)
+    img = np.zeros((3, H, W), np.uint8)
+    img[0, 10:20, 30:45] = rs.randint(1, 200, (10, 15))
+    img[1] = rs.randint(0, 256, (H, W))
+    thr = np.array([3, 250, 0], np.int32)
+    idx, cnt = hip.fg_compact(torch.from_numpy(img).to(DEV), torch.from_numpy(thr).to(DEV), 4096)
+    idx, cnt = idx.cpu().numpy(), cnt.cpu().numpy()
+    for k in range(3):
+        exp = np.flatnonzero(img[k].ravel() > thr[k])
+        assert cnt[k] == len(exp)
+        assert np.array_equal(np.sort(idx[k, :cnt[k]]), exp)
+    # overflow is reported through the true count
+    idx, cnt = hip.fg_compact(torch.from_numpy(img[1:2]).to(DEV), torch.from_numpy(np.array([10], np.int32)).to(DEV), 64)
+    assert cnt.item() == int((img[1] > 10).sum()) > 64
+
+
+def test_full_size_properties():
+    """BASELINE-size checks that need no oracle: linearity of the histogram total, D == 0 for identical
+    frames, and store / no-store agreement on a 1280x1024 stack."""
+    W, H, F = 1280, 1024, 8
+    spec = synth.EventSpec(F, t0=4, bubbles=[(640, 512, 40)])
+    fr = synth.render_event(W, H, spec, 11, 0, xp="torch", device=DEV)
+    sg = torch.ones((1, H, W), dtype=torch.uint8, device=DEV)
+    s6 = hip.sigma6(sg)
+    jobs = hip.stack_jobs(1, F, 1, F - 1, 2, 1, DEV)
+    h1, D = hip.diff_hist(fr, s6, jobs, W, H, store=True)
+    h2, _ = hip.diff_hist(fr, s6, jobs, W, H, store=False)
+    assert torch.equal(h1, h2)
+    assert (h1.sum(1) == W * H).all()
+    for k in range(F - 1):
+        assert torch.equal(torch.bincount(D[k].flatten().long(), minlength=256).int(), h1[k])
+    same = hip.make_jobs([(3, 3, 0, 0)], DEV)
+    h, D0 = hip.diff_hist(fr, s6, same, W, H, store=True)
+    assert int(h[0, 0]) == W * H and not D0.any()
+    # the bubble (contrast 40 > 6 sigma) shows up from its genesis frame on and is centred correctly
+    nz = D[spec.t0 - 1].nonzero()
+    assert len(nz) > 0
+    assert abs(nz[:, 0].float().mean().item() - 512) < 1.0 and abs(nz[:, 1].float().mean().item() - 640) < 1.0
