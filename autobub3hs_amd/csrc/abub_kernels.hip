@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/abub_hip.h"
@@ -201,24 +202,18 @@ struct RowIn {
 template <int NDW>
 __device__ __forceinline__ void k2_load_row(RowIn<NDW> &R, const uint8_t *__restrict__ cur,
                                             const uint8_t *__restrict__ ref,
-                                            const uint8_t *__restrict__ sg, int y, int W, int xoff,
-                                            bool active)
+                                            const uint8_t *__restrict__ sg, int y, int W, int xoff)
 {
-    if (active) {
-        size_t o = (size_t)y * W + xoff;
-        const uint32_t *pc = reinterpret_cast<const uint32_t *>(cur + o);
-        const uint32_t *pr = reinterpret_cast<const uint32_t *>(ref + o);
-        const uint32_t *ps = reinterpret_cast<const uint32_t *>(sg + o);
+    // xoff is clamped to a valid column for idle lanes by the caller: no branch, no exec masking
+    size_t o = (size_t)y * W + xoff;
+    const uint32_t *pc = reinterpret_cast<const uint32_t *>(cur + o);
+    const uint32_t *pr = reinterpret_cast<const uint32_t *>(ref + o);
+    const uint32_t *ps = reinterpret_cast<const uint32_t *>(sg + o);
 #pragma unroll
-        for (int d = 0; d < NDW; d++) {
-            R.c[d] = pc[d];
-            R.r[d] = pr[d];
-            R.s[d] = ps[d];
-        }
-    } else {
-#pragma unroll
-        for (int d = 0; d < NDW; d++)
-            R.c[d] = R.r[d] = R.s[d] = 0;
+    for (int d = 0; d < NDW; d++) {
+        R.c[d] = pc[d];
+        R.r[d] = pr[d];
+        R.s[d] = ps[d];
     }
 }
 
@@ -326,8 +321,11 @@ __device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, bool
     }
 }
 
-template <int NDW, bool STORE>
-__global__ __launch_bounds__(64) void k2_rows(const uint8_t *__restrict__ frames,
+#ifndef K2_WAVES_PER_EU
+#define K2_WAVES_PER_EU 1
+#endif
+template <int NDW, bool STORE, int PF>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER_EU))) void k2_rows(const uint8_t *__restrict__ frames,
                                               const uint8_t *__restrict__ sigma6,
                                               const abub_job *__restrict__ jobs, int W, int H,
                                               int rows_per_chunk, int nchunks,
@@ -349,7 +347,7 @@ __global__ __launch_bounds__(64) void k2_rows(const uint8_t *__restrict__ frames
     const bool active = lane < nl;
     const bool first_lane = lane == 0;
     const bool last_lane = lane == nl - 1;
-    const int xoff = lane * 4 * NDW;
+    const int xoff = active ? lane * 4 * NDW : 0; // idle lanes shadow lane 0 (results unused)
 
     const int y0 = chunk * rows_per_chunk;
     int y1 = y0 + rows_per_chunk;
@@ -370,26 +368,28 @@ __global__ __launch_bounds__(64) void k2_rows(const uint8_t *__restrict__ frames
 
     uint8_t *dbase = STORE ? diff + (size_t)jb.out * P + xoff : nullptr;
 
-    // two row buffers, manually unrolled by two so that neither the prefetch buffers nor the
-    // accumulators need register moves at the loop back-edge
-    RowIn<NDW> ra, rb;
-    k2_load_row<NDW>(ra, cur, ref, sg, reflect101(y0 - 2, H), W, xoff, active);
-    for (int t = 0; t < T; t += 2) {
-        {
-            int tn = t + 1 < T ? t + 1 : t;
-            k2_load_row<NDW>(rb, cur, ref, sg, reflect101(y0 - 2 + tn, H), W, xoff, active);
-        }
-        {
-            int y = y0 + t - 4;
-            k2_row<NDW, STORE>(ra, A, t >= 4, active, first_lane, last_lane, lh,
-                               reinterpret_cast<uint32_t *>(dbase + (ptrdiff_t)y * W));
-        }
-        if (t + 1 < T) {
-            int tn = t + 2 < T ? t + 2 : t + 1;
-            k2_load_row<NDW>(ra, cur, ref, sg, reflect101(y0 - 2 + tn, H), W, xoff, active);
-            int y = y0 + t + 1 - 4;
-            k2_row<NDW, STORE>(rb, A, t + 1 >= 4, active, first_lane, last_lane, lh,
-                               reinterpret_cast<uint32_t *>(dbase + (ptrdiff_t)y * W));
+    // Software prefetch PF rows ahead through a ring of PF+1 row buffers.  The loop is unrolled by
+    // U = lcm(PF+1, 2) so that ring slots are compile-time registers and neither the ring nor the
+    // vertical accumulators (ping-pong period 2) need register moves at the back-edge.
+    constexpr int RING = PF + 1;
+    constexpr int U = (RING % 2 == 0) ? RING : 2 * RING;
+    RowIn<NDW> ring[RING];
+#pragma unroll
+    for (int k = 0; k < PF; k++) {
+        int tk = k < T ? k : T - 1;
+        k2_load_row<NDW>(ring[k], cur, ref, sg, reflect101(y0 - 2 + tk, H), W, xoff);
+    }
+    for (int t = 0; t < T; t += U) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int tt = t + u;
+            if (tt < T) {
+                int tn = tt + PF < T ? tt + PF : T - 1;
+                k2_load_row<NDW>(ring[(u + PF) % RING], cur, ref, sg, reflect101(y0 - 2 + tn, H), W, xoff);
+                int y = y0 + tt - 4;
+                k2_row<NDW, STORE>(ring[u % RING], A, tt >= 4, active, first_lane, last_lane, lh,
+                                   reinterpret_cast<uint32_t *>(dbase + (ptrdiff_t)y * W));
+            }
         }
     }
 
@@ -482,18 +482,42 @@ static int pick_ndw(int W)
     return 0;
 }
 
+template <int NDW, int PF>
+static void launch_k2_rows_pf(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
+                              int njobs, int W, int H, int R, int nchunks, uint32_t *hist, uint8_t *diff,
+                              hipStream_t st)
+{
+    dim3 grid((unsigned)njobs * nchunks), block(64);
+    if (diff)
+        hipLaunchKernelGGL((k2_rows<NDW, true, PF>), grid, block, 0, st, frames, sigma6, jobs, W, H, R,
+                           nchunks, hist, diff);
+    else
+        hipLaunchKernelGGL((k2_rows<NDW, false, PF>), grid, block, 0, st, frames, sigma6, jobs, W, H, R,
+                           nchunks, hist, diff);
+}
+
+static int k2_prefetch_depth()
+{
+    static int pf = -1;
+    if (pf < 0) {
+        const char *e = getenv("ABUB_K2_PF"); // tuning knob (1..3); default chosen from measurements
+        pf = e ? atoi(e) : 1; // measured on MI355X: PF=1 keeps 3 waves/SIMD and wins (profiles/r01_*)
+        if (pf < 1 || pf > 3)
+            pf = 1;
+    }
+    return pf;
+}
+
 template <int NDW>
 static void launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
                            int njobs, int W, int H, int R, int nchunks, uint32_t *hist, uint8_t *diff,
                            hipStream_t st)
 {
-    dim3 grid((unsigned)njobs * nchunks), block(64);
-    if (diff)
-        hipLaunchKernelGGL((k2_rows<NDW, true>), grid, block, 0, st, frames, sigma6, jobs, W, H, R,
-                           nchunks, hist, diff);
-    else
-        hipLaunchKernelGGL((k2_rows<NDW, false>), grid, block, 0, st, frames, sigma6, jobs, W, H, R,
-                           nchunks, hist, diff);
+    switch (k2_prefetch_depth()) {
+    case 2: launch_k2_rows_pf<NDW, 2>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
+    case 3: launch_k2_rows_pf<NDW, 3>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
+    default: launch_k2_rows_pf<NDW, 1>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
+    }
 }
 
 extern "C" int abub_diff_hist_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
