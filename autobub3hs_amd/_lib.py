@@ -47,6 +47,7 @@ SIGNATURES = {
     "abub_ctx_upload_stack": (_i, [_vp, C.POINTER(_vp), _i]),
     "abub_ctx_diff_hist_batch": (_i, [_vp, _i, _i, _i, _vp]),
     "abub_ctx_diff_frame": (_i, [_vp, _i, _i, _vp, _vp]),
+    "abub_ctx_diff_frame_roi": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "abub_ctx_posttrig": (_i, [_vp, _i, _vp, _vp]),
     "abub_ctx_foreground": (_i, [_vp, _i, _vp, _i, C.POINTER(_i)]),
     "abub_ctx_fetch_image": (_i, [_vp, _vp]),

@@ -254,6 +254,25 @@ extern "C" int abub_ctx_diff_frame(abub_ctx *c, int i, int ref, uint8_t *D_out, 
     return finish_image(c, D_out, hist_out);
 }
 
+extern "C" int abub_ctx_diff_frame_roi(abub_ctx *c, int i, int ref, int rx, int ry, int rw, int rh,
+                                       uint8_t *D_out, uint32_t *hist_out)
+{
+    if (!c || i < 0 || ref < 0 || i >= c->F || ref >= c->F)
+        return cfail(ABUB_E_INVALID, "abub_ctx_diff_frame_roi: frame index out of range");
+    if (!c->have_model)
+        return cfail(ABUB_E_INVALID, "abub_ctx_diff_frame_roi: no model set");
+    CCHK(hipSetDevice(c->device));
+    // the generic kernel addresses ref relative to cur; order the pair so that the offset is >= 0
+    const uint8_t *pc = c->d_frames + (size_t)i * c->P, *pr = c->d_frames + (size_t)ref * c->P;
+    if (ref >= i) {
+        CALL(abub_diff_roi_dev(pc, pr, c->d_sigma6, c->W, c->H, rx, ry, rw, rh, c->d_img, c->d_hist, c->stream));
+    } else {
+        // |G(pos)-G(neg)| is symmetric in (cur, ref): swapping the frames swaps the two planes only
+        CALL(abub_diff_roi_dev(pr, pc, c->d_sigma6, c->W, c->H, rx, ry, rw, rh, c->d_img, c->d_hist, c->stream));
+    }
+    return finish_image(c, D_out, hist_out);
+}
+
 extern "C" int abub_ctx_posttrig(abub_ctx *c, int i, uint8_t *O_out, uint32_t *hist_out)
 {
     if (!c || i < 0 || i >= c->F)

@@ -1,0 +1,208 @@
+"""ctypes front-end of libabub_host.so: the C++ mirror of the reference's AnalyzerUnit / L3Localizer /
+Trainer API (include/abub3hs/) driven the way AutoBubStart3.cpp drives it.  Fails loudly when the
+native library is missing; nothing here computes on the CPU what the GPU path should compute."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libabub_host.so")
+
+_u8p = C.POINTER(C.c_uint8)
+_u32p = C.POINTER(C.c_uint32)
+_ip = C.POINTER(C.c_int)
+_dp = C.POINTER(C.c_double)
+_lib = None
+
+
+def build(force=False):
+    from . import _lib as hiplib
+
+    hiplib.build(force)
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "host"), "-s"])
+    return SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            raise RuntimeError(f"{SO} is missing: run __graft_entry__.build()")
+        L = C.CDLL(SO)
+        L.abh_run_new.restype = C.c_void_p
+        L.abh_run_free.argtypes = [C.c_void_p]
+        L.abh_run_add_event.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, _u8p]
+        L.abh_train.argtypes = [C.c_void_p, C.c_int, _ip, _ip, _u8p, _u8p]
+        L.abh_set_model.argtypes = [C.c_void_p, C.c_int, _u8p, _u8p, C.c_int, C.c_int, C.c_int]
+        L.abh_analyze.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p]
+        for f in ("trig", "status", "loc_thres", "ok", "nbubbles"):
+            getattr(L, "abh_last_" + f).argtypes = [C.c_void_p]
+        L.abh_last_error.argtypes = [C.c_void_p]
+        L.abh_last_error.restype = C.c_char_p
+        L.abh_last_ndesc.argtypes = [C.c_void_p, C.c_int]
+        L.abh_last_desc.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
+        L.abh_last_ndz.argtypes = [C.c_void_p, C.c_int]
+        L.abh_last_dz.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.abh_last_dz.restype = C.c_float
+        L.abh_last_dzdt.argtypes = [C.c_void_p, C.c_int]
+        L.abh_last_dzdt.restype = C.c_float
+        L.abh_last_drdt.argtypes = [C.c_void_p, C.c_int]
+        L.abh_last_drdt.restype = C.c_float
+        L.abh_contours.argtypes = [_u32p, C.c_int, C.c_int, C.c_int, _ip, _ip, C.c_int, C.c_int]
+        L.abh_binarize_threshold.argtypes = [_u32p, C.c_int, C.c_int]
+        L.abh_entropy.argtypes = [_u32p, C.c_int, C.c_int]
+        L.abh_entropy.restype = C.c_float
+        L.abh_blob_stats.argtypes = [_ip, C.c_int, _dp]
+        L.abh_sig_new.restype = C.c_void_p
+        L.abh_sig_free.argtypes = [C.c_void_p]
+        L.abh_sig_eval.argtypes = [C.c_void_p, _u32p, C.c_int, C.c_int, C.c_int, _ip]
+        L.abh_sig_eval.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+DESC_KEYS = ("x", "y", "w", "h", "area", "radius", "m00", "m10", "m01", "cx", "cy")
+
+
+class Run:
+    """An in-memory run: events added per camera, trained, then analysed per (event, camera)."""
+
+    def __init__(self):
+        self._h = lib().abh_run_new()
+
+    def close(self):
+        if self._h:
+            lib().abh_run_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_event(self, event, cam, frames, ok=None):
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        F, H, W = frames.shape
+        okp = None
+        if ok is not None:
+            ok = np.ascontiguousarray(ok, dtype=np.uint8)
+            okp = ok.ctypes.data_as(_u8p)
+        lib().abh_run_add_event(self._h, str(event).encode(), cam, frames.ctypes.data_as(_u8p), F, W, H, okp)
+        self._shape = (H, W)
+
+    def train(self, cam):
+        H, W = self._shape
+        mu = np.zeros((H, W), np.uint8)
+        sg = np.zeros((H, W), np.uint8)
+        st, tss = C.c_int(), C.c_int()
+        rc = lib().abh_train(self._h, cam, C.byref(st), C.byref(tss), mu.ctypes.data_as(_u8p), sg.ctypes.data_as(_u8p))
+        if rc != 0:
+            raise RuntimeError(lib().abh_last_error(self._h).decode())
+        return st.value, tss.value, mu, sg
+
+    def set_model(self, cam, mu, sigma, tss):
+        mu = np.ascontiguousarray(mu, dtype=np.uint8)
+        sigma = np.ascontiguousarray(sigma, dtype=np.uint8)
+        H, W = mu.shape
+        lib().abh_set_model(self._h, cam, mu.ctypes.data_as(_u8p), sigma.ctypes.data_as(_u8p), W, H, int(tss))
+
+    def analyze(self, event, cam, maskdir=""):
+        L = lib()
+        staged = L.abh_analyze(self._h, str(event).encode(), cam, maskdir.encode())
+        if staged == -100:
+            raise RuntimeError(L.abh_last_error(self._h).decode())
+        state = {"trig": L.abh_last_trig(self._h), "status": L.abh_last_status(self._h),
+                 "ok": bool(L.abh_last_ok(self._h)), "loc_thres": L.abh_last_loc_thres(self._h)}
+        bubbles = []
+        buf = (C.c_double * 11)()
+        for b in range(L.abh_last_nbubbles(self._h)):
+            descs = []
+            for d in range(L.abh_last_ndesc(self._h, b)):
+                L.abh_last_desc(self._h, b, d, buf)
+                dd = dict(zip(DESC_KEYS, list(buf)))
+                for k in ("x", "y", "w", "h"):
+                    dd[k] = int(dd[k])
+                descs.append(dd)
+            dz = [L.abh_last_dz(self._h, b, i) for i in range(L.abh_last_ndz(self._h, b))]
+            bubbles.append({"desc": descs, "dz": dz, "dzdt": L.abh_last_dzdt(self._h, b),
+                            "drdt": L.abh_last_drdt(self._h, b)})
+        return staged, state, bubbles, L.abh_last_error(self._h).decode()
+
+
+# ---- host-logic probes (CPU only) ---------------------------------------------------------------
+def contours_from_indices(idx, W, H):
+    idx = np.ascontiguousarray(idx, dtype=np.uint32)
+    npts = np.zeros(4096, np.int32)
+    xy = np.zeros((1 << 18, 2), np.int32)
+    n = lib().abh_contours(idx.ctypes.data_as(_u32p), len(idx), W, H, npts.ctypes.data_as(_ip),
+                           xy.ctypes.data_as(_ip), len(npts), len(xy))
+    if n < 0:
+        raise RuntimeError("contour probe capacity exceeded")
+    out, o = [], 0
+    for k in range(n):
+        out.append(xy[o:o + npts[k]].copy())
+        o += npts[k]
+    return out
+
+
+def binarize_threshold(hist, P, tozero):
+    hist = np.ascontiguousarray(hist, dtype=np.uint32)
+    return int(lib().abh_binarize_threshold(hist.ctypes.data_as(_u32p), int(P), int(tozero)))
+
+
+def entropy(hist, nbins, P):
+    hist = np.ascontiguousarray(hist, dtype=np.uint32)
+    return float(lib().abh_entropy(hist.ctypes.data_as(_u32p), nbins, int(P)))
+
+
+def blob_stats(xy):
+    xy = np.ascontiguousarray(xy, dtype=np.int32)
+    out = (C.c_double * 8)()
+    lib().abh_blob_stats(xy.ctypes.data_as(_ip), len(xy), out)
+    return dict(zip(("x", "y", "w", "h", "area", "m00", "m10", "m01"), list(out)))
+
+
+class Significance:
+    def __init__(self, tss):
+        self._h = lib().abh_sig_new()
+        self.tss = tss
+        self.loc_thres = C.c_int(3)
+
+    def __call__(self, hist, P, store):
+        hist = np.ascontiguousarray(hist, dtype=np.uint32)
+        return float(lib().abh_sig_eval(self._h, hist.ctypes.data_as(_u32p), int(P), 1 if store else 0, self.tss,
+                                        C.byref(self.loc_thres)))
+
+    def __del__(self):
+        try:
+            lib().abh_sig_free(self._h)
+        except Exception:
+            pass
+
+
+def smoke(orc):
+    """One small event end to end through the C++ API mirror on cuda:0, checked against the oracle."""
+    from . import synth
+
+    W, H, F = 640, 256, 24
+    spec = synth.EventSpec(F, t0=12, bubbles=[(300, 120, 40)])
+    fr = synth.render_event(W, H, spec, 7, 0)
+    tr = synth.training_pairs(W, H, 6, 0, F)
+    run = Run()
+    for e in range(6):
+        run.add_event(e, 0, np.concatenate([tr[2 * e:2 * e + 2], tr[2 * e:2 * e + 2], tr[2 * e:2 * e + 2]]))
+    st, tss, mu, sg = run.train(0)
+    mu_r, sg_r = orc.welford(tr)
+    assert st == 0 and tss == 12 and np.array_equal(mu, mu_r) and np.array_equal(sg, sg_r)
+    run.add_event(100, 0, fr)
+    staged, state, bubbles, err = run.analyze(100, 0)
+    a = orc.Analyzer(fr, mu_r, sg_r, tss)
+    staged_r, state_r, bubbles_r = a.any_cam_analysis()
+    assert (staged, state) == (staged_r, state_r), (staged, state, staged_r, state_r, err)
+    assert len(bubbles) == len(bubbles_r) and all(
+        [tuple(d[k] for k in "xywh") for d in b["desc"]] == [tuple(d[k] for k in "xywh") for d in r["desc"]]
+        for b, r in zip(bubbles, bubbles_r))
+    run.close()

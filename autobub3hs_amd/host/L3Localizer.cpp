@@ -1,0 +1,238 @@
+// L3Localizer.cpp -- genesis-frame blob extraction and <=10-frame tracking.  Decisions follow the
+// reference's BubbleLocalizer/L3Localizer.cpp (cited per function); images never leave HBM: the GPU
+// returns a histogram (for the Otsu threshold) and the compacted foreground pixel list, from which
+// the host traces the contours.
+#include "BubbleLocalizer/L3Localizer.hpp"
+
+#include <cmath>
+#include <iostream>
+#include <stdexcept>
+
+#include "common/CommonParameters.h"
+#include "devctx.hpp"
+#include "hostlogic.hpp"
+
+L3Localizer::L3Localizer(std::string EventID, std::string ImageDir, int CameraNumber, bool nonStopPref,
+                         Trainer **TrainedData, std::string MaskDir, Parser *Parser)
+    : AnalyzerUnit(EventID, ImageDir, CameraNumber, TrainedData, MaskDir, Parser)
+{
+    nonStopMode = nonStopPref;
+    color = cv::Scalar(255, 255, 255);
+    color_red = cv::Scalar(0, 0, 255);
+    color_orange = cv::Scalar(0, 140, 255);
+    color_green = cv::Scalar(0, 255, 0);
+    Level1SuspicionFlag = false;
+    numBubbleMultiplicity = 0;
+    topCutCornerX = topCutCornerY = 0;
+    blur_diam = 5;
+}
+
+L3Localizer::~L3Localizer()
+{
+    std::cout << "Releasing memory\n"; // L3Localizer.cpp:79
+}
+
+// threshold (TOZERO tozeroThr, then BINARY|OTSU) + external contours of the context's current image
+static thread_local abub::ContourFinder t_finder;
+
+static void contoursOfCurrentImage(abub::EventOnDevice &ev, const uint32_t *hist, int tozeroThr,
+                                   std::vector<std::vector<cv::Point>> &contours)
+{
+    const int thr = abub::binarizeThresholdFromHist(hist, (size_t)ev.W * ev.H, tozeroThr);
+    std::vector<uint32_t> fg;
+    ev.foreground(thr, fg);
+    t_finder.find(fg, ev.W, ev.H, contours);
+}
+
+static BubbleImageFrame describe(const std::vector<cv::Point> &contour, const cv::Rect &box, bool genesisFallback)
+{
+    BubbleImageFrame f;
+    f.ContArea = abub::contourAreaOf(contour);
+    f.newPosition = box;
+    f.moments = abub::momentsOf(contour);
+    f.ContRadius = std::sqrt(f.ContArea / 3.14159);
+    if (!genesisFallback || f.moments.m00 > 0) {
+        f.MassCentres = cv::Point2f((float)(f.moments.m10 / f.moments.m00), (float)(f.moments.m01 / f.moments.m00));
+    } else {
+        // degenerate polygon: mean of the vertices (L3Localizer.cpp:409-418)
+        double x = 0, y = 0, n = 0;
+        for (const cv::Point &p : contour) {
+            x += p.x;
+            y += p.y;
+            n++;
+        }
+        f.MassCentres = cv::Point2f((float)(x / n), (float)(y / n));
+    }
+    return f;
+}
+
+// L3Localizer.cpp:215-460.  The bellows-template subtraction (:303-369, "next" row 3 of the scope
+// table) is not implemented: when every contour lies in the bellows mask the code takes the
+// reference's "template not loadable" branch (:297-301): contours are re-found and kept.
+void L3Localizer::CalculateInitialBubbleParams(void)
+{
+    abub::EventOnDevice &ev = device();
+    const int prevOffset = (TrainedData->TrainingSetSize < 6) ? 1 : 2;
+    int pre = MatTrigFrame - prevOffset;
+    if (pre < 0)
+        pre = 0;
+    const uint32_t *hist = ev.diffFrame(MatTrigFrame, pre);
+    std::vector<std::vector<cv::Point>> contours;
+    contoursOfCurrentImage(ev, hist, loc_thres, contours);
+
+    std::vector<cv::Rect> minRect(contours.size());
+    int largestBoxArea = 0;
+    bool allInBellowsMask = !contours.empty();
+    {
+        std::vector<std::vector<cv::Point>> kept;
+        std::vector<cv::Rect> keptRect;
+        for (size_t i = 0; i < contours.size(); i++) {
+            cv::Rect r = abub::boundingRectOf(contours[i]);
+            if (!isInMask(&r, true)) {
+                allInBellowsMask = false;
+                largestBoxArea = std::max(largestBoxArea, r.width * r.height);
+                kept.push_back(contours[i]);
+                keptRect.push_back(r);
+            } else if (!nonStopMode)
+                std::cout << "Found bubble in bellows mask." << std::endl;
+        }
+        if (allInBellowsMask) {
+            std::cout << "Template image not loadable for event " << EventID << " camera " << CameraNumber
+                      << "; cannot veto bellows movement triggers" << std::endl;
+            largestBoxArea = 0;
+            minRect.clear();
+            for (auto &c : contours) {
+                minRect.push_back(abub::boundingRectOf(c));
+                largestBoxArea = std::max(largestBoxArea, minRect.back().width * minRect.back().height);
+            }
+        } else {
+            contours.swap(kept);
+            minRect.swap(keptRect);
+        }
+    }
+    for (size_t i = 0; i < contours.size(); i++) {
+        const int BoxArea = minRect[i].width * minRect[i].height;
+        if (BoxArea > 10 || BoxArea >= largestBoxArea) {
+            bubbleRects.push_back(minRect[i]);
+            BubbleImageFrame f = describe(contours[i], minRect[i], true);
+            if (!isInMask(&f.newPosition))
+                continue; // genesis outside the fiducial mask
+            BubbleList.push_back(new bubble(f));
+        }
+    }
+}
+
+// L3Localizer.cpp:764-869
+void L3Localizer::CalculatePostTriggerFrameParams(int postTrigFrameNumber)
+{
+    abub::EventOnDevice &ev = device();
+    const int frame = MatTrigFrame + postTrigFrameNumber;
+    if (!ev.frameOk(frame))
+        throw std::runtime_error("L3Localizer: undecodable post-trigger frame");
+    const uint32_t *hist = ev.postTrig(frame);
+    std::vector<std::vector<cv::Point>> contours;
+    contoursOfCurrentImage(ev, hist, 3, contours);
+
+    std::vector<BubbleImageFrame> sightings;
+    for (auto &c : contours) {
+        cv::Rect r = abub::boundingRectOf(c);
+        if (r.width * r.height > 10) {
+            BubbleImageFrame f = describe(c, r, false);
+            if (!isInMask(&f.newPosition))
+                continue;
+            sightings.push_back(f);
+        }
+    }
+    for (bubble *b : BubbleList)
+        b->lockThisIteration = false;
+    // first bubble whose last position is close enough takes the sighting; the search stops there
+    // even if that bubble was already served this frame (L3Localizer.cpp:847-863)
+    for (BubbleImageFrame &s : sightings) {
+        const float x = s.MassCentres.x, y = s.MassCentres.y;
+        for (bubble *b : BubbleList) {
+            const float bx = b->last_x, by = b->last_y;
+            if ((bx - x < 5) && (std::fabs(by - y) < 5)) {
+                *b << s;
+                break;
+            }
+        }
+    }
+}
+
+void L3Localizer::printBubbleList(void)
+{
+    for (bubble *b : BubbleList)
+        b->printAllXY();
+}
+
+// L3Localizer.cpp:881-968
+void L3Localizer::LocalizeOMatic(std::string)
+{
+    if (CameraFrames.size() <= 5)
+        okToProceed = false;
+    if (!okToProceed)
+        return;
+    abub::EventOnDevice &ev = device();
+    const int prevOffset = (TrainedData->TrainingSetSize < 6) ? 1 : 2;
+    int preTrigNum = MatTrigFrame - prevOffset;
+    if (preTrigNum < 0)
+        preTrigNum = 0;
+    if (!ev.frameOk(MatTrigFrame) || !ev.frameOk(preTrigNum) || !ev.frameOk(0))
+        throw std::runtime_error("L3Localizer::LocalizeOMatic: undecodable trigger / pre-trigger frame");
+    triggerFrame = ev.frames[MatTrigFrame];
+    preTrigFrame = ev.frames[preTrigNum];
+    presentationFrame = triggerFrame.clone();
+    ComparisonFrame = ev.frames[0];
+
+    CalculateInitialBubbleParams();
+
+    const int last = (MatTrigFrame < 29) ? NumFramesBubbleTrack : (39 - MatTrigFrame);
+    for (int k = 1; k <= last; k++) {
+        if ((size_t)(MatTrigFrame + k) >= CameraFrames.size())
+            break;
+        CalculatePostTriggerFrameParams(k);
+    }
+}
+
+// L3Localizer.cpp:971-1012.  Lookups outside the mask image (unchecked upstream) count as "outside".
+bool L3Localizer::isInMask(cv::Rect *genesis_coords, bool bellows)
+{
+    const int xpix = (int)(genesis_coords->x + genesis_coords->width / 2.);
+    const int ypix = genesis_coords->y + genesis_coords->height / 2;
+    if (MaskDir == "")
+        return !bellows;
+    std::string path = MaskDir + "/cam" + std::to_string(CameraNumber);
+    if (bellows)
+        path += "_bellows";
+    path += "_mask.bmp";
+    if (bellows && bellows_mask.empty() && !bellows_mask_tried) {
+        bellows_mask = cv::imread(path, cv::IMREAD_GRAYSCALE);
+        bellows_mask_tried = true;
+    } else if (!bellows && cam_mask.empty() && !cam_mask_tried) {
+        cam_mask = cv::imread(path, cv::IMREAD_GRAYSCALE);
+        cam_mask_tried = true;
+    }
+    const cv::Mat &mask = bellows ? bellows_mask : cam_mask;
+    if (mask.empty()) {
+        std::cout << "Mask image not loadable for event " << EventID << " camera " << CameraNumber << "; skipping mask check" << std::endl;
+        return !bellows;
+    }
+    if (xpix < 0 || ypix < 0 || xpix >= mask.cols || ypix >= mask.rows)
+        return false;
+    return (int)mask.at<uchar>(ypix, xpix) > 0;
+}
+
+// ---- entry points that exist upstream but belong to rows outside the current scope --------------
+cv::Rect L3Localizer::GetDiffROI(cv::Point2f p1, cv::Point2f p2, cv::Mat &frame)
+{
+    int sx = (int)std::max(p1.x, p2.x), sy = (int)std::max(p1.y, p2.y);
+    int dx = (int)(std::min(p1.x, p2.x) + frame.cols - sx), dy = (int)(std::min(p1.y, p2.y) + frame.rows - sy);
+    return cv::Rect(sx, sy, dx, dy);
+}
+void L3Localizer::TrackAFeature(cv::Mat &, cv::Mat, cv::Point2f &)
+{
+    throw std::runtime_error("L3Localizer::TrackAFeature (bellows template matching) is not implemented yet (scope row 8f #3)");
+}
+void L3Localizer::CalculateInitialBubbleParamsCam2(void) {}      // dead upstream (L3Localizer.cpp:547)
+void L3Localizer::CalculatePostTriggerFrameParamsCam2(int) {}    // dead upstream
+bool bubbleBRectSort(cv::RotatedRect a, cv::RotatedRect b) { return a.center.y < b.center.y; }

@@ -1,0 +1,247 @@
+// capi.cpp -- small C surface over the C++ API mirror so that the Python test-suite and bench.py can
+// drive Trainer / L3Localizer exactly the way the reference's main() does (AutoBubStart3.cpp:294-307,
+// :363-364 and AnyCamAnalysis :67-125).  Not part of the drop-in boundary.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <exception>
+#include <iostream>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "AlgorithmTraining/Trainer.hpp"
+#include "AnalyzerUnit.hpp"
+#include "BubbleLocalizer/L3Localizer.hpp"
+#include "ParseFolder/Parser.hpp"
+#include "devctx.hpp"
+#include "hostlogic.hpp"
+
+namespace {
+
+struct BubbleOut {
+    std::vector<BubbleImageFrame> desc;
+    std::vector<float> dz;
+    float dzdt, drdt;
+};
+
+struct Run {
+    MemParser parser;
+    std::map<int, Trainer *> trainers;
+    // last analysis
+    int staged = 0, trig = 0, status = 0, loc_thres = 0, ok = 0;
+    std::vector<BubbleOut> bubbles;
+    std::string error;
+};
+
+// AnyCamAnalysis (AutoBubStart3.cpp:87-117): retry until a bubble is found or the search fails.
+int anyCamAnalysis(AnalyzerUnit *A, Run *run)
+{
+    int staged = 0;
+    try {
+        do {
+            A->FindTriggerFrame(true, A->MatTrigFrame + 1);
+            if (A->okToProceed) {
+                A->LocalizeOMatic("");
+                if (A->okToProceed)
+                    staged = A->BubbleList.empty() ? -1 : 0; // stageCameraOutput (PICOFormatWriterV4.cpp:99-110)
+                else {
+                    staged = -8;
+                    break;
+                }
+            } else {
+                staged = A->TriggerFrameIdentificationStatus;
+                break;
+            }
+        } while (A->BubbleList.size() == 0);
+    } catch (std::exception &e) {
+        run->error = e.what();
+        std::cout << e.what() << '\n';
+        staged = -6;
+    }
+    return staged;
+}
+
+} // namespace
+
+extern "C" {
+
+void *abh_run_new() { return new Run(); }
+
+void abh_run_free(void *r)
+{
+    Run *run = (Run *)r;
+    for (auto &kv : run->trainers)
+        delete kv.second;
+    delete run;
+    abub::DeviceContext::releaseThread();
+}
+
+// frames: [F][H][W]; ok: F flags or NULL
+int abh_run_add_event(void *r, const char *ev, int cam, const uint8_t *frames, int F, int W, int H, const uint8_t *ok)
+{
+    Run *run = (Run *)r;
+    std::vector<cv::Mat> v;
+    for (int k = 0; k < F; ++k) {
+        cv::Mat m;
+        if (!ok || ok[k]) {
+            m.create(H, W, CV_8U);
+            std::memcpy(m.data, frames + (size_t)k * W * H, (size_t)W * H);
+        }
+        v.push_back(m);
+    }
+    run->parser.AddFrames(ev, cam, v);
+    return 0;
+}
+
+// Trainer over every event of the run (numeric order like AutoBubStart3.cpp:284)
+int abh_train(void *r, int cam, int *status, int *tss, uint8_t *mu_out, uint8_t *sigma_out)
+{
+    Run *run = (Run *)r;
+    try {
+        std::vector<std::string> events;
+        run->parser.GetEventDirLists(events);
+        std::sort(events.begin(), events.end(), [](const std::string &a, const std::string &b) { return std::stoi(a) < std::stoi(b); });
+        delete run->trainers[cam];
+        Trainer *t = new Trainer(cam, events, "", "cam%d_image%u.png", "", run->parser.clone(), false);
+        run->trainers[cam] = t;
+        t->MakeAvgSigmaImage(false);
+        *status = t->StatusCode;
+        *tss = t->TrainingSetSize;
+        if (t->StatusCode == 0 && mu_out && sigma_out) {
+            std::memcpy(mu_out, t->TrainedAvgImage.data, t->TrainedAvgImage.total());
+            std::memcpy(sigma_out, t->TrainedSigmaImage.data, t->TrainedSigmaImage.total());
+        }
+        return 0;
+    } catch (std::exception &e) {
+        run->error = e.what();
+        return -1;
+    }
+}
+
+// install a model directly (tests that want a specific mu/sigma/TrainingSetSize)
+int abh_set_model(void *r, int cam, const uint8_t *mu, const uint8_t *sigma, int W, int H, int tss)
+{
+    Run *run = (Run *)r;
+    static unsigned long long next = 1ull << 40;
+    delete run->trainers[cam];
+    Trainer *t = new Trainer(cam, {}, "", "cam%d_image%u.png", "", run->parser.clone(), false);
+    t->TrainedAvgImage.create(H, W, CV_8U);
+    t->TrainedSigmaImage.create(H, W, CV_8U);
+    std::memcpy(t->TrainedAvgImage.data, mu, (size_t)W * H);
+    std::memcpy(t->TrainedSigmaImage.data, sigma, (size_t)W * H);
+    t->TrainingSetSize = tss;
+    t->ModelId = next++;
+    run->trainers[cam] = t;
+    return 0;
+}
+
+int abh_analyze(void *r, const char *ev, int cam, const char *maskdir)
+{
+    Run *run = (Run *)r;
+    run->bubbles.clear();
+    run->error.clear();
+    auto it = run->trainers.find(cam);
+    if (it == run->trainers.end() || !it->second) {
+        run->error = "no trainer for camera";
+        return -100;
+    }
+    Trainer *t = it->second;
+    AnalyzerUnit *A = nullptr;
+    try {
+        A = new L3Localizer(ev, "", cam, true, &t, maskdir ? maskdir : "", run->parser.clone());
+    } catch (std::exception &e) {
+        run->error = e.what();
+        return -100;
+    }
+    run->staged = anyCamAnalysis(A, run);
+    run->trig = A->MatTrigFrame;
+    run->status = A->TriggerFrameIdentificationStatus;
+    run->loc_thres = A->loc_thres;
+    run->ok = A->okToProceed;
+    for (bubble *b : A->BubbleList) {
+        BubbleOut o;
+        o.desc = b->KnownDescriptors;
+        o.dz = b->dz;
+        o.dzdt = b->dZdT();
+        o.drdt = b->dRdT();
+        run->bubbles.push_back(o);
+    }
+    delete A;
+    return run->staged;
+}
+
+int abh_last_trig(void *r) { return ((Run *)r)->trig; }
+int abh_last_status(void *r) { return ((Run *)r)->status; }
+int abh_last_loc_thres(void *r) { return ((Run *)r)->loc_thres; }
+int abh_last_ok(void *r) { return ((Run *)r)->ok; }
+const char *abh_last_error(void *r) { return ((Run *)r)->error.c_str(); }
+int abh_last_nbubbles(void *r) { return (int)((Run *)r)->bubbles.size(); }
+int abh_last_ndesc(void *r, int b) { return (int)((Run *)r)->bubbles[b].desc.size(); }
+// out: x,y,w,h,area,radius,m00,m10,m01,cx,cy
+void abh_last_desc(void *r, int b, int d, double *out)
+{
+    const BubbleImageFrame &f = ((Run *)r)->bubbles[b].desc[d];
+    out[0] = f.newPosition.x;
+    out[1] = f.newPosition.y;
+    out[2] = f.newPosition.width;
+    out[3] = f.newPosition.height;
+    out[4] = f.ContArea;
+    out[5] = f.ContRadius;
+    out[6] = f.moments.m00;
+    out[7] = f.moments.m10;
+    out[8] = f.moments.m01;
+    out[9] = f.MassCentres.x;
+    out[10] = f.MassCentres.y;
+}
+int abh_last_ndz(void *r, int b) { return (int)((Run *)r)->bubbles[b].dz.size(); }
+float abh_last_dz(void *r, int b, int i) { return ((Run *)r)->bubbles[b].dz[i]; }
+float abh_last_dzdt(void *r, int b) { return ((Run *)r)->bubbles[b].dzdt; }
+float abh_last_drdt(void *r, int b) { return ((Run *)r)->bubbles[b].drdt; }
+
+// host-logic probes for CPU-side unit tests (no GPU needed)
+int abh_contours(const uint32_t *idx, int n, int W, int H, int *npts_out, int *xy_out, int cap_contours, int cap_pts)
+{
+    std::vector<uint32_t> v(idx, idx + n);
+    std::vector<std::vector<cv::Point>> cs;
+    abub::ContourFinder f;
+    f.find(v, W, H, cs);
+    int k = 0, used = 0;
+    for (auto &c : cs) {
+        if (k >= cap_contours || used + (int)c.size() > cap_pts)
+            return -1;
+        npts_out[k++] = (int)c.size();
+        for (auto &p : c) {
+            xy_out[2 * used] = p.x;
+            xy_out[2 * used + 1] = p.y;
+            ++used;
+        }
+    }
+    return k;
+}
+int abh_binarize_threshold(const uint32_t *hist, int P, int tozero) { return abub::binarizeThresholdFromHist(hist, (size_t)P, tozero); }
+float abh_entropy(const uint32_t *hist, int nbins, int P) { return abub::entropyFromHist(hist, nbins, (size_t)P); }
+void abh_blob_stats(const int *xy, int n, double *out /*x,y,w,h,area,m00,m10,m01*/)
+{
+    std::vector<cv::Point> pts;
+    for (int i = 0; i < n; ++i)
+        pts.push_back(cv::Point(xy[2 * i], xy[2 * i + 1]));
+    cv::Rect r = abub::boundingRectOf(pts);
+    cv::Moments m = abub::momentsOf(pts);
+    out[0] = r.x;
+    out[1] = r.y;
+    out[2] = r.width;
+    out[3] = r.height;
+    out[4] = abub::contourAreaOf(pts);
+    out[5] = m.m00;
+    out[6] = m.m10;
+    out[7] = m.m01;
+}
+// significance state machine probe: feeds histograms sequentially
+void *abh_sig_new() { return new std::vector<std::vector<int>>(256); }
+void abh_sig_free(void *s) { delete (std::vector<std::vector<int>> *)s; }
+double abh_sig_eval(void *s, const uint32_t *hist, int P, int store, int tss, int *loc_thres)
+{
+    return abub::significanceFromHist(*(std::vector<std::vector<int>> *)s, hist, (size_t)P, store != 0, tss, 3, *loc_thres);
+}
+}

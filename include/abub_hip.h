@@ -133,6 +133,10 @@ int abub_ctx_diff_hist_batch(abub_ctx *ctx, int ref_offset, int first, int count
  * The image stays resident as the context's "current image" for abub_ctx_foreground. */
 int abub_ctx_diff_frame(abub_ctx *ctx, int i, int ref, uint8_t *D_out, uint32_t *hist_out);
 
+/* ROI overload of ProcessFrame on resident frames (AnalyzerUnit.cpp:346, bellows path L3Localizer.cpp:355). */
+int abub_ctx_diff_frame_roi(abub_ctx *ctx, int i, int ref, int rx, int ry, int rw, int rh, uint8_t *D_out,
+                            uint32_t *hist_out);
+
 /* Post-trigger image of frame i (L3Localizer.cpp:779-785) + histogram; becomes the current image. */
 int abub_ctx_posttrig(abub_ctx *ctx, int i, uint8_t *O_out, uint32_t *hist_out);
 

@@ -1,0 +1,213 @@
+"""End-to-end parity on the GPU: whole (event, camera) analyses through the C++ mirror of the reference
+API (Trainer / L3Localizer driven like AutoBubStart3.cpp's AnyCamAnalysis) versus the CPU oracle.
+Integers, status codes and boxes must match bit for bit; centroids/radii within 1e-4 (they are the
+same double arithmetic on identical polygons)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from autobub3hs_amd import host, synth  # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    host.build()
+
+
+def write_bmp8(path, img):
+    """8-bit palettised BMP (grey palette), bottom-up -- the format of cam_masks/*.bmp."""
+    H, W = img.shape
+    stride = (W + 3) // 4 * 4
+    pal = b"".join(struct.pack("<BBBB", i, i, i, 0) for i in range(256))
+    data = b"".join(img[y].tobytes() + b"\0" * (stride - W) for y in range(H - 1, -1, -1))
+    off = 14 + 40 + len(pal)
+    with open(path, "wb") as f:
+        f.write(b"BM" + struct.pack("<IHHI", off + len(data), 0, 0, off))
+        f.write(struct.pack("<IiiHHIIiiII", 40, W, H, 1, 8, 0, len(data), 2835, 2835, 256, 0))
+        f.write(pal + data)
+
+
+def write_bmp1(path, img):
+    """1-bit BMP, palette {black, white}."""
+    H, W = img.shape
+    stride = ((W + 31) // 32) * 4
+    rows = []
+    for y in range(H - 1, -1, -1):
+        bits = np.packbits((img[y] > 0).astype(np.uint8))
+        rows.append(bits.tobytes() + b"\0" * (stride - len(bits)))
+    data = b"".join(rows)
+    pal = struct.pack("<BBBB", 0, 0, 0, 0) + struct.pack("<BBBB", 255, 255, 255, 0)
+    off = 14 + 40 + len(pal)
+    with open(path, "wb") as f:
+        f.write(b"BM" + struct.pack("<IHHI", off + len(data), 0, 0, off))
+        f.write(struct.pack("<IiiHHIIiiII", 40, W, H, 1, 1, 0, len(data), 2835, 2835, 2, 0))
+        f.write(pal + data)
+
+
+def compare(res, ref):
+    staged, state, bubbles, err = res
+    staged_r, state_r, bubbles_r = ref
+    assert staged == staged_r, (staged, staged_r, err)
+    assert state == state_r
+    assert len(bubbles) == len(bubbles_r)
+    for b, r in zip(bubbles, bubbles_r):
+        assert len(b["desc"]) == len(r["desc"])
+        for d, e in zip(b["desc"], r["desc"]):
+            assert tuple(d[k] for k in "xywh") == tuple(e[k] for k in "xywh")
+            for k in ("area", "radius", "m00", "m10", "m01", "cx", "cy"):
+                if np.isnan(e[k]):
+                    assert np.isnan(d[k])
+                else:
+                    assert abs(d[k] - e[k]) <= 1e-4 * max(1.0, abs(e[k])), (k, d[k], e[k])
+        assert b["dz"] == pytest.approx(r["dz"], nan_ok=True)
+        assert b["dzdt"] == pytest.approx(r["dzdt"], nan_ok=True) and b["drdt"] == pytest.approx(r["drdt"], nan_ok=True)
+
+
+def oracle_event(oracle, fr, mu, sg, tss, **kw):
+    a = oracle.Analyzer(fr, mu, sg, tss, **kw)
+    out = a.any_cam_analysis()
+    a.close()
+    return out
+
+
+def run_with_model(frames_by_event, mu, sg, tss, cam=0):
+    run = host.Run()
+    for ev, fr in frames_by_event.items():
+        if isinstance(fr, tuple):
+            run.add_event(ev, cam, fr[0], ok=fr[1])
+        else:
+            run.add_event(ev, cam, fr)
+    run.set_model(cam, mu, sg, tss)
+    return run
+
+
+@pytest.mark.parametrize("W,H", [(640, 256), (1280, 200), (322, 150)])
+def test_events_trained_on_gpu(oracle, W, H):
+    F, cam, nev = 30, 0, 8
+    run = host.Run()
+    stacks = {}
+    for e in range(nev):
+        spec = synth.random_spec(W, H, F, e, cam, p_second=0.5, margin=30)
+        stacks[e] = (spec, synth.render_event(W, H, spec, e, cam))
+        run.add_event(e, cam, stacks[e][1])
+    # one event with a disturbed second frame: vetoed by the 16-bin entropy test (Trainer.cpp:287)
+    bad = synth.render_event(W, H, synth.EventSpec(F, t0=1, bubbles=[(W // 2, H // 2, 90)]), 99, cam)
+    bad[1, H // 4:3 * H // 4, W // 4:3 * W // 4] = np.clip(bad[1, H // 4:3 * H // 4, W // 4:3 * W // 4].astype(int) + 60, 0, 255)
+    run.add_event(99, cam, bad)
+    st, tss, mu, sg = run.train(cam)
+    good = [stacks[e][1][:2] for e in range(nev)]
+    assert oracle.pair_entropy16(bad[1], bad[0]) > 0.0005
+    assert all(oracle.pair_entropy16(g[1], g[0]) <= 0.0005 for g in good)
+    mu_r, sg_r = oracle.welford(np.concatenate(good))
+    assert st == 0 and tss == 2 * nev
+    assert np.array_equal(mu, mu_r) and np.array_equal(sg, sg_r)
+    for e in range(nev):
+        spec, fr = stacks[e]
+        res = run.analyze(e, cam)
+        ref = oracle_event(oracle, fr, mu_r, sg_r, tss)
+        compare(res, ref)
+        assert res[0] == 0 and res[1]["trig"] in (spec.t0, spec.t0 + 1)
+    run.close()
+
+
+def test_small_training_set_one_frame_offset(oracle):
+    W, H, F = 640, 200, 28
+    spec = synth.EventSpec(F, t0=13, bubbles=[(200, 100, -40)])
+    fr = synth.render_event(W, H, spec, 3, 1)
+    tr = synth.training_pairs(W, H, 2, 1, F)  # 4 frames < 6: threshold 5.0, one-frame offset, loc_thres 3
+    mu, sg = oracle.welford(tr)
+    run = run_with_model({5: fr}, mu, sg, len(tr), cam=1)
+    compare(run.analyze(5, 1), oracle_event(oracle, fr, mu, sg, len(tr)))
+    run.close()
+
+
+def test_status_codes(oracle):
+    W, H = 320, 128
+    tr = synth.training_pairs(W, H, 6, 0, 20)
+    mu, sg = oracle.welford(tr)
+    quiet = synth.render_event(W, H, synth.EventSpec(20), 1, 0)
+    short4 = quiet[:4]
+    five = synth.render_event(W, H, synth.EventSpec(5, t0=2, bubbles=[(100, 60, 40)]), 2, 0)
+    bub = synth.render_event(W, H, synth.EventSpec(20, t0=10, bubbles=[(100, 60, 40)]), 3, 0)
+    ok = np.ones(20, np.uint8)
+    ok[4] = 0
+    run = run_with_model({1: quiet, 2: short4, 3: five, 4: (bub, ok)}, mu, sg, len(tr))
+    r = run.analyze(1, 0)
+    assert r[0] == -3
+    compare(r, oracle_event(oracle, quiet, mu, sg, len(tr)))
+    r = run.analyze(2, 0)
+    assert r[0] == -9
+    compare(r, oracle_event(oracle, short4, mu, sg, len(tr)))
+    r = run.analyze(3, 0)
+    assert r[0] == -8
+    compare(r, oracle_event(oracle, five, mu, sg, len(tr)))
+    r = run.analyze(4, 0)
+    assert r[0] == -9
+    compare(r, oracle_event(oracle, bub, mu, sg, len(tr), frame_ok=ok))
+    run.close()
+
+
+def test_noisy_sigma_zero_flicker_and_retry(oracle):
+    W, H, F = 256, 96, 36
+    sg = np.zeros((H, W), np.uint8)
+    spec = synth.EventSpec(F, t0=22, bubbles=[(120, 50, -40)], flicker=9, flicker_adu=12)
+    fr = synth.render_event(W, H, spec, 3, 1)
+    run = run_with_model({1: fr}, fr[0], sg, 20, cam=1)
+    res = run.analyze(1, 1)
+    compare(res, oracle_event(oracle, fr, fr[0], sg, 20))
+    # persistent +1 step without any blob above threshold: retried until the end (-3) or a late blob
+    fr2 = synth.render_event(W, H, synth.EventSpec(30), 4, 1)
+    fr2[12:] = np.clip(fr2[12:].astype(int) + 1, 0, 255).astype(np.uint8)
+    run.add_event(2, 1, fr2)
+    compare(run.analyze(2, 1), oracle_event(oracle, fr2, fr[0], sg, 20))
+    run.close()
+
+
+def test_masks_from_bmp_files(oracle, tmp_path):
+    W, H, F = 640, 256, 30
+    spec = synth.EventSpec(F, t0=12, bubbles=[(300, 120, 40), (520, 60, 40)])
+    fr = synth.render_event(W, H, spec, 9, 0)
+    tr = synth.training_pairs(W, H, 6, 0, F)
+    mu, sg = oracle.welford(tr)
+    fid = np.full((300, 700), 255, np.uint8)
+    fid[100:140, 280:320] = 0  # first bubble outside the fiducial volume
+    bel = np.zeros((300, 700), np.uint8)
+    bel[40:80, 500:540] = 200  # second bubble inside the bellows region
+    write_bmp1(os.path.join(tmp_path, "cam0_mask.bmp"), fid)
+    write_bmp8(os.path.join(tmp_path, "cam0_bellows_mask.bmp"), bel)
+    run = run_with_model({1: fr}, mu, sg, len(tr))
+    res = run.analyze(1, 0, maskdir=str(tmp_path))
+    ref = oracle_event(oracle, fr, mu, sg, len(tr), fid_mask=fid, bel_mask=bel)
+    compare(res, ref)
+    # only a bellows mask that covers everything: contours are re-found and kept (no template)
+    os.remove(os.path.join(tmp_path, "cam0_mask.bmp"))
+    write_bmp8(os.path.join(tmp_path, "cam0_bellows_mask.bmp"), np.full((300, 700), 255, np.uint8))
+    res = run.analyze(1, 0, maskdir=str(tmp_path))
+    ref = oracle_event(oracle, fr, mu, sg, len(tr), bel_mask=np.full((300, 700), 255, np.uint8))
+    compare(res, ref)
+    assert res[0] == 0 and len(res[2]) == 2
+    run.close()
+
+
+def test_many_random_events_parity(oracle):
+    """30 seeded events with two cameras' worth of seeds, 1280-wide (fast kernel) frames."""
+    W, H, F = 1280, 160, 41
+    tr = synth.training_pairs(W, H, 10, 0, F)
+    mu, sg = oracle.welford(tr)
+    run = host.Run()
+    run.set_model(0, mu, sg, len(tr))
+    n_ok = 0
+    for e in range(30):
+        spec = synth.random_spec(W, H, F, 1000 + e, 0, p_second=0.4, p_none=0.15, p_flicker=0.3, margin=25)
+        fr = synth.render_event(W, H, spec, 1000 + e, 0)
+        run.add_event(e, 0, fr)
+        res = run.analyze(e, 0)
+        compare(res, oracle_event(oracle, fr, mu, sg, len(tr)))
+        n_ok += res[0] == 0
+    assert n_ok >= 20
+    run.close()
