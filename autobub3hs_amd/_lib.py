@@ -39,6 +39,7 @@ SIGNATURES = {
     "abub_pair_hist_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "abub_posttrig_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "abub_fg_compact_dev": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "abub_fg_compact_pairs_dev": (_i, [_vp, _i, _i, _i, _vp, _vp, C.c_uint32, _vp, _vp]),
     "abub_ctx_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i]),
     "abub_ctx_destroy": (None, [_vp]),
     "abub_ctx_train": (_i, [_vp, C.POINTER(_vp), _i, _vp, _vp]),

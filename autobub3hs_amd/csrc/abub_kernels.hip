@@ -871,3 +871,73 @@ extern "C" int abub_fg_compact_dev(const uint8_t *img, int nimg, int W, int H, c
     HIPCHK(hipGetLastError());
     return ABUB_OK;
 }
+
+// K4 batched: shared (image, index) pair list
+__global__ __launch_bounds__(256) void k4_compact_pairs(const uint8_t *__restrict__ img, size_t P,
+                                                        const int32_t *__restrict__ thr,
+                                                        uint32_t *__restrict__ pairs, uint32_t cap,
+                                                        uint32_t *__restrict__ count)
+{
+    const uint32_t k = blockIdx.y;
+    const uint8_t *im = img + (size_t)k * P;
+    const int t = thr[k];
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    if ((P & 15) == 0) {
+        size_t nv = P / 16;
+        for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nv; q += stride) {
+            uint4 w = reinterpret_cast<const uint4 *>(im)[q];
+            uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                if (ww[d] == 0)
+                    continue;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    int v = (ww[d] >> (8 * b)) & 0xff;
+                    if (v > t) {
+                        uint32_t pos = atomicAdd(count, 1u);
+                        if (pos < cap) {
+                            pairs[2 * (size_t)pos] = k;
+                            pairs[2 * (size_t)pos + 1] = (uint32_t)(q * 16 + d * 4 + b);
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
+            if ((int)im[i] > t) {
+                uint32_t pos = atomicAdd(count, 1u);
+                if (pos < cap) {
+                    pairs[2 * (size_t)pos] = k;
+                    pairs[2 * (size_t)pos + 1] = (uint32_t)i;
+                }
+            }
+        }
+    }
+}
+
+extern "C" int abub_fg_compact_pairs_dev(const uint8_t *img, int nimg, int W, int H, const int32_t *thr,
+                                         uint32_t *pairs, uint32_t cap, uint32_t *count, void *stream)
+{
+    if (!img || !thr || !pairs || !count || nimg < 0 || W <= 0 || H <= 0 || cap == 0)
+        return set_err(ABUB_E_INVALID, "abub_fg_compact_pairs_dev: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(count, 0, sizeof(uint32_t), st));
+    if (nimg == 0)
+        return ABUB_OK;
+    size_t P = (size_t)W * H;
+    int bx = (int)((P / 16 + 255) / 256);
+    if (bx < 1)
+        bx = 1;
+    if (bx > 64)
+        bx = 64;
+    for (int base = 0; base < nimg; base += 65535) {
+        int n = nimg - base < 65535 ? nimg - base : 65535;
+        if (base != 0)
+            return set_err(ABUB_E_INVALID, "abub_fg_compact_pairs_dev: nimg > 65535");
+        hipLaunchKernelGGL(k4_compact_pairs, dim3(bx, n), dim3(256), 0, st, img, P, thr, pairs, cap, count);
+    }
+    HIPCHK(hipGetLastError());
+    return ABUB_OK;
+}

@@ -206,3 +206,81 @@ def smoke(orc):
         [tuple(d[k] for k in "xywh") for d in b["desc"]] == [tuple(d[k] for k in "xywh") for d in r["desc"]]
         for b, r in zip(bubbles, bubbles_r))
     run.close()
+
+
+class Pipeline:
+    """Run-level batched detect over an HBM-resident slab [E][C][F][H][W] (host/pipeline.cpp)."""
+
+    def __init__(self, device, W, H, F, E, ncams, tss, nthreads=16, maskdir=""):
+        L = lib()
+        L.abh_pipe_new.restype = C.c_void_p
+        L.abh_pipe_new.argtypes = [C.c_int] * 6 + [_ip, C.c_int, C.c_char_p]
+        L.abh_pipe_free.argtypes = [C.c_void_p]
+        L.abh_pipe_run.argtypes = [C.c_void_p] * 5
+        L.abh_pipe_error.restype = C.c_char_p
+        L.abh_pipe_result.argtypes = [C.c_void_p, C.c_int, _ip]
+        L.abh_pipe_ndesc.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.abh_pipe_desc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp]
+        L.abh_pipe_dzdt.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.abh_pipe_dzdt.restype = C.c_float
+        L.abh_pipe_drdt.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.abh_pipe_drdt.restype = C.c_float
+        L.abh_pipe_stack_error.argtypes = [C.c_void_p, C.c_int]
+        L.abh_pipe_stack_error.restype = C.c_char_p
+        L.abh_pipe_timing.argtypes = [C.c_void_p, _dp]
+        t = (C.c_int * len(tss))(*tss)
+        self.S = E * ncams
+        self._h = L.abh_pipe_new(device, W, H, F, E, ncams, t, nthreads, maskdir.encode())
+        if not self._h:
+            raise RuntimeError("abh_pipe_new failed (see stderr)")
+
+    def close(self):
+        if self._h:
+            lib().abh_pipe_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, frames, mu, sigma6, stream=0):
+        """frames/mu/sigma6: device pointers (ints) or torch tensors."""
+        p = [x.data_ptr() if hasattr(x, "data_ptr") else int(x) for x in (frames, mu, sigma6)]
+        rc = lib().abh_pipe_run(self._h, p[0], p[1], p[2], stream)
+        if rc != 0:
+            raise RuntimeError("pipeline: " + lib().abh_pipe_error().decode())
+
+    def timing(self):
+        out = (C.c_double * 5)()
+        rounds = lib().abh_pipe_timing(self._h, out)
+        return dict(zip(("stage1_ms", "stage2_ms", "stage3_ms", "stage4_ms", "total_ms"), list(out)), rounds=rounds)
+
+    def result(self, s):
+        L = lib()
+        o = (C.c_int * 6)()
+        L.abh_pipe_result(self._h, s, o)
+        state = {"trig": o[1], "status": o[2], "ok": bool(o[4]), "loc_thres": o[3]}
+        bubbles = []
+        buf = (C.c_double * 11)()
+        for b in range(o[5]):
+            descs = []
+            for d in range(L.abh_pipe_ndesc(self._h, s, b)):
+                L.abh_pipe_desc(self._h, s, b, d, buf)
+                dd = dict(zip(DESC_KEYS, list(buf)))
+                for k in ("x", "y", "w", "h"):
+                    dd[k] = int(dd[k])
+                descs.append(dd)
+            bubbles.append({"desc": descs, "dzdt": L.abh_pipe_dzdt(self._h, s, b), "drdt": L.abh_pipe_drdt(self._h, s, b)})
+        return o[0], state, bubbles, L.abh_pipe_stack_error(self._h, s).decode()
+
+    def summary(self):
+        """(staged, trig, nbubbles) for every stack -- cheap fingerprint of a run."""
+        L = lib()
+        o = (C.c_int * 6)()
+        out = []
+        for s in range(self.S):
+            L.abh_pipe_result(self._h, s, o)
+            out.append((o[0], o[1], o[5]))
+        return out

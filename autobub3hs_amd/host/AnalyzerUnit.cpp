@@ -33,25 +33,27 @@ AnalyzerUnit::~AnalyzerUnit(void)
 {
     for (bubble *b : BubbleList)
         delete b;
-    if (dev) {
-        // the context must forget a stack whose owner goes away
-        try {
-            abub::DeviceContext &dc = abub::DeviceContext::forThread(dev->W ? dev->W : 1, dev->H ? dev->H : 1, 1);
-            if (dc.residentEvent == dev)
-                dc.residentEvent = nullptr;
-        } catch (...) {
-        }
+    if (dev && ownsDev)
         delete dev;
-    }
     delete TrainedData;
     delete FileParser;
 }
 
-abub::EventOnDevice &AnalyzerUnit::device()
+abub::EventData &AnalyzerUnit::device()
 {
-    if (!dev)
+    if (!dev) {
         dev = new abub::EventOnDevice(FileParser, EventID, CameraFrames, TrainedData);
+        ownsDev = true;
+    }
     return *dev;
+}
+
+void AnalyzerUnit::AttachEventData(abub::EventData *data)
+{
+    if (dev && ownsDev)
+        delete dev;
+    dev = data;
+    ownsDev = false;
 }
 
 // The frame list comes from the Parser in the constructor; this legacy entry point re-reads it.
@@ -151,7 +153,7 @@ void AnalyzerUnit::FindTriggerFrame(bool nonStopMode, int startframe)
     if (!nonStopMode)
         std::cout << "twoFrameOffset: " << twoFrameOffset << "; this->TrainedData->TrainingSetSize: " << TrainedData->TrainingSetSize << std::endl;
 
-    abub::EventOnDevice &ev = device();
+    abub::EventData &ev = device();
     const size_t P = (size_t)ev.W * ev.H;
     auto significance = [&](int frame, bool store) {
         return abub::significanceFromHist(pix_counts, ev.diffHist(frame, refOffset), P, store,

@@ -6,7 +6,11 @@
 
 #include <cmath>
 #include <iostream>
+#include <map>
+#include <mutex>
 #include <stdexcept>
+
+#include <sys/stat.h>
 
 #include "common/CommonParameters.h"
 #include "devctx.hpp"
@@ -27,15 +31,20 @@ L3Localizer::L3Localizer(std::string EventID, std::string ImageDir, int CameraNu
     blur_diam = 5;
 }
 
+namespace abub {
+bool g_quietAnalyzers = false; // batched drivers switch the per-analyzer chatter off
+}
+
 L3Localizer::~L3Localizer()
 {
-    std::cout << "Releasing memory\n"; // L3Localizer.cpp:79
+    if (!abub::g_quietAnalyzers)
+        std::cout << "Releasing memory\n"; // L3Localizer.cpp:79
 }
 
 // threshold (TOZERO tozeroThr, then BINARY|OTSU) + external contours of the context's current image
 static thread_local abub::ContourFinder t_finder;
 
-static void contoursOfCurrentImage(abub::EventOnDevice &ev, const uint32_t *hist, int tozeroThr,
+static void contoursOfCurrentImage(abub::EventData &ev, const uint32_t *hist, int tozeroThr,
                                    std::vector<std::vector<cv::Point>> &contours)
 {
     const int thr = abub::binarizeThresholdFromHist(hist, (size_t)ev.W * ev.H, tozeroThr);
@@ -71,7 +80,7 @@ static BubbleImageFrame describe(const std::vector<cv::Point> &contour, const cv
 // reference's "template not loadable" branch (:297-301): contours are re-found and kept.
 void L3Localizer::CalculateInitialBubbleParams(void)
 {
-    abub::EventOnDevice &ev = device();
+    abub::EventData &ev = device();
     const int prevOffset = (TrainedData->TrainingSetSize < 6) ? 1 : 2;
     int pre = MatTrigFrame - prevOffset;
     if (pre < 0)
@@ -97,7 +106,8 @@ void L3Localizer::CalculateInitialBubbleParams(void)
                 std::cout << "Found bubble in bellows mask." << std::endl;
         }
         if (allInBellowsMask) {
-            std::cout << "Template image not loadable for event " << EventID << " camera " << CameraNumber
+            if (!abub::g_quietAnalyzers)
+                std::cout << "Template image not loadable for event " << EventID << " camera " << CameraNumber
                       << "; cannot veto bellows movement triggers" << std::endl;
             largestBoxArea = 0;
             minRect.clear();
@@ -125,7 +135,7 @@ void L3Localizer::CalculateInitialBubbleParams(void)
 // L3Localizer.cpp:764-869
 void L3Localizer::CalculatePostTriggerFrameParams(int postTrigFrameNumber)
 {
-    abub::EventOnDevice &ev = device();
+    abub::EventData &ev = device();
     const int frame = MatTrigFrame + postTrigFrameNumber;
     if (!ev.frameOk(frame))
         throw std::runtime_error("L3Localizer: undecodable post-trigger frame");
@@ -172,17 +182,17 @@ void L3Localizer::LocalizeOMatic(std::string)
         okToProceed = false;
     if (!okToProceed)
         return;
-    abub::EventOnDevice &ev = device();
+    abub::EventData &ev = device();
     const int prevOffset = (TrainedData->TrainingSetSize < 6) ? 1 : 2;
     int preTrigNum = MatTrigFrame - prevOffset;
     if (preTrigNum < 0)
         preTrigNum = 0;
     if (!ev.frameOk(MatTrigFrame) || !ev.frameOk(preTrigNum) || !ev.frameOk(0))
         throw std::runtime_error("L3Localizer::LocalizeOMatic: undecodable trigger / pre-trigger frame");
-    triggerFrame = ev.frames[MatTrigFrame];
-    preTrigFrame = ev.frames[preTrigNum];
+    triggerFrame = ev.hostFrame(MatTrigFrame); // empty when the frames only live in HBM
+    preTrigFrame = ev.hostFrame(preTrigNum);
     presentationFrame = triggerFrame.clone();
-    ComparisonFrame = ev.frames[0];
+    ComparisonFrame = ev.hostFrame(0);
 
     CalculateInitialBubbleParams();
 
@@ -192,6 +202,26 @@ void L3Localizer::LocalizeOMatic(std::string)
             break;
         CalculatePostTriggerFrameParams(k);
     }
+}
+
+// mask files are immutable during a run: decode each once per process instead of once per analyzer
+static cv::Mat cachedMask(const std::string &path)
+{
+    static std::mutex mu;
+    static std::map<std::string, cv::Mat> cache;
+    struct stat sb;
+    if (stat(path.c_str(), &sb) != 0)
+        return cv::Mat();
+    const std::string key = path + "#" + std::to_string((long long)sb.st_mtim.tv_sec) + "." +
+                            std::to_string((long long)sb.st_mtim.tv_nsec) + "#" + std::to_string((long long)sb.st_size);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end())
+        return it->second;
+    cv::Mat m = cv::imread(path, cv::IMREAD_GRAYSCALE);
+    if (!m.empty())
+        cache[key] = m;
+    return m;
 }
 
 // L3Localizer.cpp:971-1012.  Lookups outside the mask image (unchecked upstream) count as "outside".
@@ -206,10 +236,10 @@ bool L3Localizer::isInMask(cv::Rect *genesis_coords, bool bellows)
         path += "_bellows";
     path += "_mask.bmp";
     if (bellows && bellows_mask.empty() && !bellows_mask_tried) {
-        bellows_mask = cv::imread(path, cv::IMREAD_GRAYSCALE);
+        bellows_mask = cachedMask(path);
         bellows_mask_tried = true;
     } else if (!bellows && cam_mask.empty() && !cam_mask_tried) {
-        cam_mask = cv::imread(path, cv::IMREAD_GRAYSCALE);
+        cam_mask = cachedMask(path);
         cam_mask_tried = true;
     }
     const cv::Mat &mask = bellows ? bellows_mask : cam_mask;

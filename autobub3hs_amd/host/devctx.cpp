@@ -95,6 +95,13 @@ EventOnDevice::EventOnDevice(Parser *parser, const std::string &eventID,
     std::memset(lastHist_, 0, sizeof lastHist_);
 }
 
+EventOnDevice::~EventOnDevice()
+{
+    // the context must forget a stack whose owner goes away
+    if (t_ctx && t_ctx->residentEvent == this)
+        t_ctx->residentEvent = nullptr;
+}
+
 DeviceContext &EventOnDevice::resident()
 {
     if (W == 0)

@@ -32,25 +32,44 @@ public:
     ~DeviceContext();
 };
 
-// Decoded frames of one (event, camera) plus everything the trigger search needs from the GPU.
-class EventOnDevice {
+// What the analysis classes need from the GPU for one (event, camera).  Two providers exist:
+// EventOnDevice (below: decodes through the Parser, uploads into the per-thread context, one call at
+// a time -- the drop-in path) and the batched provider of RunPipeline (pipeline.cpp: every stack of a
+// run is already resident in HBM and all launches are shared across events).
+class EventData {
+public:
+    virtual ~EventData() {}
+    int F = 0, W = 0, H = 0;
+    virtual bool frameOk(int i) const = 0;
+    // host copy of frame i, or an empty Mat when the frames only exist in HBM
+    virtual cv::Mat hostFrame(int i) const = 0;
+    // histogram of D(frame[i]; frame[max(i-refOffset,0)])
+    virtual const uint32_t *diffHist(int i, int refOffset) = 0;
+    // D(frame[i]; frame[ref]) becomes the current image; returns its histogram
+    virtual const uint32_t *diffFrame(int i, int ref, cv::Mat *out = nullptr) = 0;
+    virtual const uint32_t *diffFrameROI(int i, int ref, cv::Rect roi, cv::Mat *out = nullptr) = 0;
+    // post-trigger image of frame i becomes the current image; returns its histogram
+    virtual const uint32_t *postTrig(int i, cv::Mat *out = nullptr) = 0;
+    // foreground (v > thr) raster indices of the current image
+    virtual void foreground(int thr, std::vector<uint32_t> &idx) = 0;
+};
+
+// Decoded frames of one (event, camera), pushed through the per-thread context on demand.
+class EventOnDevice : public EventData {
 public:
     EventOnDevice(Parser *parser, const std::string &eventID, const std::vector<std::string> &frameNames,
                   const Trainer *model);
-    int F = 0, W = 0, H = 0;
+    ~EventOnDevice() override;
     std::vector<cv::Mat> frames; // empty Mat == Parser::GetImage returned -1
-    bool frameOk(int i) const { return i >= 0 && i < F && !frames[i].empty(); }
+    bool frameOk(int i) const override { return i >= 0 && i < F && !frames[i].empty(); }
+    cv::Mat hostFrame(int i) const override { return frames[i]; }
 
-    // histogram of D(frame[i]; frame[max(i-refOffset,0)]); all frames are evaluated in one batched
-    // launch the first time any of them is asked for
-    const uint32_t *diffHist(int i, int refOffset);
-    // D(frame[i]; frame[ref]) becomes the context's current image; returns its histogram
-    const uint32_t *diffFrame(int i, int ref, cv::Mat *out = nullptr);
-    const uint32_t *diffFrameROI(int i, int ref, cv::Rect roi, cv::Mat *out = nullptr);
-    // post-trigger image of frame i becomes the current image; returns its histogram
-    const uint32_t *postTrig(int i, cv::Mat *out = nullptr);
-    // foreground (v > thr) raster indices of the current image
-    void foreground(int thr, std::vector<uint32_t> &idx);
+    // all frames are evaluated in one batched launch the first time any histogram is asked for
+    const uint32_t *diffHist(int i, int refOffset) override;
+    const uint32_t *diffFrame(int i, int ref, cv::Mat *out = nullptr) override;
+    const uint32_t *diffFrameROI(int i, int ref, cv::Rect roi, cv::Mat *out = nullptr) override;
+    const uint32_t *postTrig(int i, cv::Mat *out = nullptr) override;
+    void foreground(int thr, std::vector<uint32_t> &idx) override;
 
 private:
     DeviceContext &resident();

@@ -15,7 +15,7 @@
 #define MIN_IMAGE_SIZE 100000
 
 namespace abub {
-class EventOnDevice; // frame stack + histograms of this analyzer, resident in HBM
+class EventData; // GPU-side view of this analyzer's frame stack (host/devctx.hpp)
 }
 
 class AnalyzerUnit {
@@ -39,9 +39,11 @@ protected:
 
     Parser *FileParser;
 
-    // decode + upload the stack and compute every diff histogram once (lazy, first use)
-    abub::EventOnDevice *dev = nullptr;
-    abub::EventOnDevice &device();
+    // GPU-side data of this (event, camera): created lazily from the Parser (decode + upload + one
+    // batched histogram pass), or injected by a run-level pipeline that already holds the frames in HBM
+    abub::EventData *dev = nullptr;
+    bool ownsDev = true;
+    abub::EventData &device();
 
 public:
     AnalyzerUnit(std::string EventID, std::string ImageDir, int CameraNumber, Trainer **TrainedData,
@@ -65,6 +67,9 @@ public:
     std::vector<double> entropies;
 
     void FindTriggerFrame(bool nonStopMode, int startframe);
+
+    // not in the reference: lets a batched driver supply the GPU-side data (not owned)
+    void AttachEventData(abub::EventData *data);
 
     virtual void LocalizeOMatic(std::string) = 0;
     std::vector<cv::Rect> bubbleRects;

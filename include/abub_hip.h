@@ -101,6 +101,11 @@ int abub_posttrig_dev(const uint8_t *frames, const uint8_t *mu, const uint8_t *s
 int abub_fg_compact_dev(const uint8_t *img, int nimg, int W, int H, const int32_t *thr,
                         uint32_t *idx, int cap, uint32_t *count, void *stream);
 
+/* K4, batched form: one shared output list of (image, raster index) pairs for all nimg images,
+ * pairs[2*k] = image number, pairs[2*k+1] = y*W+x (unordered); *count = true total (may exceed cap). */
+int abub_fg_compact_pairs_dev(const uint8_t *img, int nimg, int W, int H, const int32_t *thr,
+                              uint32_t *pairs, uint32_t cap, uint32_t *count, void *stream);
+
 /* ------------------------------------------------------------------------------------------- */
 /* (B) context API (host buffers in/out)                                                       */
 /* ------------------------------------------------------------------------------------------- */
