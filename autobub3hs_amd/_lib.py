@@ -39,6 +39,10 @@ SIGNATURES = {
     "abub_pair_hist_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "abub_posttrig_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "abub_fg_compact_dev": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "abub_fast_path": (_i, [_i]),
+    "abub_diff_hist_compact_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp]),
+    "abub_posttrig_compact_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp]),
+    "abub_pairs_group_dev": (_i, [_vp, _vp, C.c_uint32, _i, _vp, _vp, _vp, _vp, _vp]),
     "abub_fg_compact_pairs_dev": (_i, [_vp, _i, _i, _i, _vp, _vp, C.c_uint32, _vp, _vp]),
     "abub_ctx_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i]),
     "abub_ctx_destroy": (None, [_vp]),

@@ -217,6 +217,48 @@ __device__ __forceinline__ void k2_load_row(RowIn<NDW> &R, const uint8_t *__rest
     }
 }
 
+// Optional fused compaction: pixels with value > thr are appended to one shared list as
+// (slot | value << 24, raster index).  Lives entirely in the rare non-zero path.
+struct Compact {
+    uint32_t *pairs;
+    uint32_t *count;
+    uint32_t cap;
+    uint32_t slot;
+    int thr;
+};
+// One atomicAdd per wave and row: every lane brings its candidate count `c`, gets back the position of
+// its first entry.  Must be called by all 64 lanes (wave-uniform control flow).  A single shared
+// counter serialises at ~90 atomics/us on MI355X, so per-pixel reservations would dominate the pass.
+__device__ __forceinline__ uint32_t compact_reserve(const Compact &cp, uint32_t c)
+{
+    const int lane = threadIdx.x;
+    uint32_t inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(inc, o);
+        if (lane >= o)
+            inc += t;
+    }
+    const uint32_t total = __shfl(inc, 63);
+    uint32_t base = 0;
+    if (total) {
+        if (lane == 0)
+            base = atomicAdd(cp.count, total);
+        base = __shfl(base, 0);
+    }
+    return base + inc - c;
+}
+__device__ __forceinline__ void compact_put(const Compact &cp, uint32_t &pos, uint32_t v, uint32_t idx)
+{
+    if ((int)v > cp.thr) {
+        if (pos < cp.cap) {
+            cp.pairs[2 * (size_t)pos] = cp.slot | (v << 24);
+            cp.pairs[2 * (size_t)pos + 1] = idx;
+        }
+        ++pos;
+    }
+}
+
 // persistent per-wave state of the vertical pass: four in-place accumulators per u16 pair and plane
 // out = a0 + X ; a0 = a1 + 4X ; a1 = a2 + 6X ; a2 = xp + 4X ; xp = X
 template <int NDW>
@@ -226,10 +268,10 @@ struct K2Acc {
 };
 
 // one input row -> one output row (valid once 5 rows went in)
-template <int NDW, bool STORE>
+template <int NDW, bool STORE, bool COMPACT>
 __device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, bool emit, bool active,
                                        bool first_lane, bool last_lane, uint32_t *lh,
-                                       uint32_t *__restrict__ po)
+                                       uint32_t *__restrict__ po, const Compact &cp, uint32_t pix0)
 {
     constexpr int NP = 2 * NDW;
     // ---- pos / neg planes as u16 pairs (AnalyzerUnit.cpp:351-352) -----------------------------
@@ -303,14 +345,33 @@ __device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, bool
     }
 
     if (emit) {
-        if (any && active) { // rare: D is zero for almost every pixel
+        const bool mine = any && active;
+        if (__builtin_amdgcn_ballot_w64(mine)) { // rare and wave-uniform: D is zero for almost every pixel
+            uint32_t pos = 0;
+            if (COMPACT) {
+                uint32_t c = 0;
+                if (mine) {
 #pragma unroll
-            for (int j = 0; j < NP; j++) {
-                uint32_t lo = Dp[j] & 0xffffu, hi = Dp[j] >> 16;
-                if (lo)
-                    atomicAdd(&lh[lo], 1u);
-                if (hi)
-                    atomicAdd(&lh[hi], 1u);
+                    for (int j = 0; j < NP; j++)
+                        c += ((int)(Dp[j] & 0xffffu) > cp.thr) + ((int)(Dp[j] >> 16) > cp.thr);
+                }
+                pos = compact_reserve(cp, c);
+            }
+            if (mine) {
+#pragma unroll
+                for (int j = 0; j < NP; j++) {
+                    uint32_t lo = Dp[j] & 0xffffu, hi = Dp[j] >> 16;
+                    if (lo) {
+                        atomicAdd(&lh[lo], 1u);
+                        if (COMPACT)
+                            compact_put(cp, pos, lo, pix0 + 2 * j);
+                    }
+                    if (hi) {
+                        atomicAdd(&lh[hi], 1u);
+                        if (COMPACT)
+                            compact_put(cp, pos, hi, pix0 + 2 * j + 1);
+                    }
+                }
             }
         }
         if (STORE && active) {
@@ -324,12 +385,14 @@ __device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, bool
 #ifndef K2_WAVES_PER_EU
 #define K2_WAVES_PER_EU 1
 #endif
-template <int NDW, bool STORE, int PF>
+template <int NDW, bool STORE, int PF, bool COMPACT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER_EU))) void k2_rows(const uint8_t *__restrict__ frames,
                                               const uint8_t *__restrict__ sigma6,
                                               const abub_job *__restrict__ jobs, int W, int H,
                                               int rows_per_chunk, int nchunks,
-                                              uint32_t *__restrict__ hist, uint8_t *__restrict__ diff)
+                                              uint32_t *__restrict__ hist, uint8_t *__restrict__ diff,
+                                              const int32_t *__restrict__ cthr, uint32_t *pairs,
+                                              uint32_t pcap, uint32_t *pcount, uint32_t slot_base)
 {
     constexpr int NP = 2 * NDW; // u16-pair registers per plane per lane
     __shared__ uint32_t lh[256];
@@ -367,6 +430,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER
         A.pa0[j] = A.pa1[j] = A.pa2[j] = A.pxp[j] = A.na0[j] = A.na1[j] = A.na2[j] = A.nxp[j] = 0;
 
     uint8_t *dbase = STORE ? diff + (size_t)jb.out * P + xoff : nullptr;
+    Compact cp;
+    cp.pairs = COMPACT ? pairs : nullptr;
+    cp.count = pcount;
+    cp.cap = pcap;
+    cp.slot = jb.out + slot_base;
+    cp.thr = COMPACT ? cthr[jb.out] : 255;
 
     // Software prefetch PF rows ahead through a ring of PF+1 row buffers.  The loop is unrolled by
     // U = lcm(PF+1, 2) so that ring slots are compile-time registers and neither the ring nor the
@@ -387,8 +456,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER
                 int tn = tt + PF < T ? tt + PF : T - 1;
                 k2_load_row<NDW>(ring[(u + PF) % RING], cur, ref, sg, reflect101(y0 - 2 + tn, H), W, xoff);
                 int y = y0 + tt - 4;
-                k2_row<NDW, STORE>(ring[u % RING], A, tt >= 4, active, first_lane, last_lane, lh,
-                                   reinterpret_cast<uint32_t *>(dbase + (ptrdiff_t)y * W));
+                k2_row<NDW, STORE, COMPACT>(ring[u % RING], A, tt >= 4, active, first_lane, last_lane, lh,
+                                   reinterpret_cast<uint32_t *>(dbase + (ptrdiff_t)y * W), cp,
+                                   (uint32_t)(y * W + xoff));
             }
         }
     }
@@ -482,47 +552,50 @@ static int pick_ndw(int W)
     return 0;
 }
 
+struct CompactArgs {
+    const int32_t *cthr;
+    uint32_t *pairs;
+    uint32_t cap;
+    uint32_t *count;
+    uint32_t slot_base; // added to job.out in the list entries (several launches share one list)
+};
+
 template <int NDW, int PF>
 static void launch_k2_rows_pf(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
                               int njobs, int W, int H, int R, int nchunks, uint32_t *hist, uint8_t *diff,
-                              hipStream_t st)
+                              const CompactArgs &ca, hipStream_t st)
 {
     dim3 grid((unsigned)njobs * nchunks), block(64);
-    if (diff)
-        hipLaunchKernelGGL((k2_rows<NDW, true, PF>), grid, block, 0, st, frames, sigma6, jobs, W, H, R,
-                           nchunks, hist, diff);
-    else
-        hipLaunchKernelGGL((k2_rows<NDW, false, PF>), grid, block, 0, st, frames, sigma6, jobs, W, H, R,
-                           nchunks, hist, diff);
-}
-
-static int k2_prefetch_depth()
-{
-    static int pf = -1;
-    if (pf < 0) {
-        const char *e = getenv("ABUB_K2_PF"); // tuning knob (1..3); default chosen from measurements
-        pf = e ? atoi(e) : 1; // measured on MI355X: PF=1 keeps 3 waves/SIMD and wins (profiles/r01_*)
-        if (pf < 1 || pf > 3)
-            pf = 1;
+#define K2_LAUNCH(ST, CO)                                                                                        \
+    hipLaunchKernelGGL((k2_rows<NDW, ST, PF, CO>), grid, block, 0, st, frames, sigma6, jobs, W, H, R, nchunks, \
+                       hist, diff, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base)
+    if (ca.cthr) {
+        if (diff)
+            K2_LAUNCH(true, true);
+        else
+            K2_LAUNCH(false, true);
+    } else {
+        if (diff)
+            K2_LAUNCH(true, false);
+        else
+            K2_LAUNCH(false, false);
     }
-    return pf;
+#undef K2_LAUNCH
 }
 
 template <int NDW>
 static void launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
                            int njobs, int W, int H, int R, int nchunks, uint32_t *hist, uint8_t *diff,
-                           hipStream_t st)
+                           const CompactArgs &ca, hipStream_t st)
 {
-    switch (k2_prefetch_depth()) {
-    case 2: launch_k2_rows_pf<NDW, 2>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
-    case 3: launch_k2_rows_pf<NDW, 3>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
-    default: launch_k2_rows_pf<NDW, 1>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
-    }
+    // prefetch depth 1 won on MI355X: depth 2/3 rings cost a wave of occupancy and ran 10-17 % slower
+    // (measured in round 1, see DESIGN.md "Tuning log")
+    launch_k2_rows_pf<NDW, 1>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st);
 }
 
-extern "C" int abub_diff_hist_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
-                                  int njobs, int W, int H, uint32_t *hist, uint8_t *diff,
-                                  int rows_per_chunk, void *stream)
+static int diff_hist_impl(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs, int njobs,
+                          int W, int H, uint32_t *hist, uint8_t *diff, int rows_per_chunk,
+                          const CompactArgs &ca, void *stream)
 {
     if (!frames || !sigma6 || !jobs || !hist || W <= 0 || H <= 0 || njobs < 0 || rows_per_chunk < 0)
         return set_err(ABUB_E_INVALID, "abub_diff_hist_dev: bad arguments");
@@ -549,16 +622,18 @@ extern "C" int abub_diff_hist_dev(const uint8_t *frames, const uint8_t *sigma6, 
         }
         int nchunks = (H + R - 1) / R;
         switch (ndw) {
-        case 1: launch_k2_rows<1>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
-        case 2: launch_k2_rows<2>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
-        case 3: launch_k2_rows<3>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
-        case 4: launch_k2_rows<4>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
-        case 5: launch_k2_rows<5>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
-        case 6: launch_k2_rows<6>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
-        case 7: launch_k2_rows<7>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
-        default: launch_k2_rows<8>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, st); break;
+        case 1: launch_k2_rows<1>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        case 2: launch_k2_rows<2>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        case 3: launch_k2_rows<3>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        case 4: launch_k2_rows<4>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        case 5: launch_k2_rows<5>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        case 6: launch_k2_rows<6>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        case 7: launch_k2_rows<7>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        default: launch_k2_rows<8>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
         }
     } else {
+        if (ca.cthr)
+            return set_err(ABUB_E_INVALID, "fused compaction needs the fast path (W % 4 == 0, W <= 2048)");
         abub_job dummy = {0, 0, 0, 0};
         dim3 grid((W + G_TW - 1) / G_TW, (H + G_TH - 1) / G_TH, njobs), block(256);
         if (grid.z > 65535)
@@ -570,6 +645,27 @@ extern "C" int abub_diff_hist_dev(const uint8_t *frames, const uint8_t *sigma6, 
     hipLaunchKernelGGL(k_hist_bin0, dim3(njobs), dim3(64), 0, st, hist, (uint32_t)((size_t)W * H));
     HIPCHK(hipGetLastError());
     return ABUB_OK;
+}
+
+extern "C" int abub_diff_hist_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
+                                  int njobs, int W, int H, uint32_t *hist, uint8_t *diff,
+                                  int rows_per_chunk, void *stream)
+{
+    CompactArgs ca = {nullptr, nullptr, 0, nullptr, 0};
+    return diff_hist_impl(frames, sigma6, jobs, njobs, W, H, hist, diff, rows_per_chunk, ca, stream);
+}
+
+extern "C" int abub_fast_path(int W) { return pick_ndw(W) != 0; }
+
+extern "C" int abub_diff_hist_compact_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
+                                          int njobs, int W, int H, uint32_t *hist, uint8_t *diff,
+                                          const int32_t *cthr, uint32_t *pairs, uint32_t cap,
+                                          uint32_t *count, uint32_t slot_base, void *stream)
+{
+    if (!cthr || !pairs || !count || cap == 0)
+        return set_err(ABUB_E_INVALID, "abub_diff_hist_compact_dev: bad arguments");
+    CompactArgs ca = {cthr, pairs, cap, count, slot_base};
+    return diff_hist_impl(frames, sigma6, jobs, njobs, W, H, hist, diff, 0, ca, stream);
 }
 
 extern "C" int abub_diff_roi_dev(const uint8_t *cur, const uint8_t *ref, const uint8_t *sigma6, int W,
@@ -783,20 +879,256 @@ __global__ __launch_bounds__(256) void k3_generic(const uint8_t *__restrict__ fr
         atomicAdd(&hist[(size_t)jb.out * 256 + tid], v);
 }
 
+// ------------------------------------------------------------------------------------------------
+// K3 fast: register-rolling rows, same lane mapping as K2.  O = sat(|f-mu| - sigma6) on u16 pairs,
+// horizontal 3-tap via one alignbit per pair, vertical 3-tap as two in-place accumulators,
+// (S+4)/9 as ((S+4)*7282)>>16 (exact for S <= 2295, checked exhaustively in tests/test_k3_div9),
+// LDS histogram and fused compaction in the rare non-zero path, optional image store.
+// ------------------------------------------------------------------------------------------------
+template <int NDW>
+struct Row3In {
+    uint32_t f[NDW], m[NDW], s[NDW];
+};
+
+template <int NDW>
+__device__ __forceinline__ void k3_load_row(Row3In<NDW> &R, const uint8_t *__restrict__ f,
+                                            const uint8_t *__restrict__ m, const uint8_t *__restrict__ sg,
+                                            int y, int W, int xoff)
+{
+    size_t o = (size_t)y * W + xoff;
+    const uint32_t *pf = reinterpret_cast<const uint32_t *>(f + o);
+    const uint32_t *pm = reinterpret_cast<const uint32_t *>(m + o);
+    const uint32_t *ps = reinterpret_cast<const uint32_t *>(sg + o);
+#pragma unroll
+    for (int d = 0; d < NDW; d++) {
+        R.f[d] = pf[d];
+        R.m[d] = pm[d];
+        R.s[d] = ps[d];
+    }
+}
+
+template <int NDW, bool STORE>
+__device__ __forceinline__ void k3_row(const Row3In<NDW> &in, uint32_t (&a0)[2 * NDW], uint32_t (&xp)[2 * NDW],
+                                       bool emit, bool active, bool first_lane, bool last_lane, uint32_t *lh,
+                                       uint32_t *__restrict__ po, const Compact &cp, uint32_t pix0)
+{
+    constexpr int NP = 2 * NDW;
+    uint32_t X[NP];
+#pragma unroll
+    for (int d = 0; d < NDW; d++) {
+        uint32_t f0 = widen_lo(in.f[d]), f1 = widen_hi(in.f[d]);
+        uint32_t m0 = widen_lo(in.m[d]), m1 = widen_hi(in.m[d]);
+        uint32_t s0 = widen_lo(in.s[d]), s1 = widen_hi(in.s[d]);
+        X[2 * d] = pk_subsat(pk_subsat(f0, m0) | pk_subsat(m0, f0), s0);     // L3Localizer.cpp:779-782
+        X[2 * d + 1] = pk_subsat(pk_subsat(f1, m1) | pk_subsat(m1, f1), s1);
+    }
+    // neighbours: only p[-1] (hi half of L) and p[n] (lo half of R) are used; reflect-101 in-lane
+    uint32_t L = __builtin_amdgcn_update_dpp(0u, X[NP - 1], DPP_WAVE_SHR1, 0xf, 0xf, false);
+    uint32_t R = __builtin_amdgcn_update_dpp(0u, X[0], DPP_WAVE_SHL1, 0xf, 0xf, false);
+    L = first_lane ? X[0] : L;       // hi half = p[1]
+    R = last_lane ? X[NP - 1] : R;   // lo half = p[n-2]
+    uint32_t w[NDW];
+    uint32_t any = 0;
+    uint32_t am1 = __builtin_amdgcn_alignbit(X[0], L, 16); // (p[-1], p[0])
+    uint32_t q[4];
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        uint32_t xp1 = j + 1 < NP ? X[j + 1] : R;
+        uint32_t ap1 = __builtin_amdgcn_alignbit(xp1, X[j], 16); // (p[2j+1], p[2j+2])
+        uint32_t h = am1 + X[j] + ap1;                            // cv::blur row sum (:785)
+        am1 = ap1;
+        uint32_t v = a0[j] + h + 0x00040004u; // S + 4 in both lanes
+        a0[j] = xp[j] + h;
+        xp[j] = h;
+        q[(j & 1) * 2] = __umul24(v & 0xffffu, 7282u);   // result in byte 2
+        q[(j & 1) * 2 + 1] = __umul24(v >> 16, 7282u);
+        if (j & 1) {
+            uint32_t w01 = __builtin_amdgcn_perm(q[1], q[0], 0x0c0c0602u);
+            uint32_t w23 = __builtin_amdgcn_perm(q[3], q[2], 0x06020c0cu);
+            w[j >> 1] = w01 | w23;
+            any |= w[j >> 1];
+        }
+    }
+    if (emit) {
+        const bool mine = any && active;
+        if (__builtin_amdgcn_ballot_w64(mine)) {
+            uint32_t pos = 0;
+            if (cp.pairs) {
+                uint32_t c = 0;
+                if (mine) {
+#pragma unroll
+                    for (int d = 0; d < NDW; d++)
+#pragma unroll
+                        for (int b = 0; b < 4; b++)
+                            c += (int)((w[d] >> (8 * b)) & 0xffu) > cp.thr;
+                }
+                pos = compact_reserve(cp, c);
+            }
+            if (mine) {
+#pragma unroll
+                for (int d = 0; d < NDW; d++) {
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        uint32_t v = (w[d] >> (8 * b)) & 0xffu;
+                        if (v) {
+                            atomicAdd(&lh[v], 1u);
+                            if (cp.pairs)
+                                compact_put(cp, pos, v, pix0 + 4 * d + b);
+                        }
+                    }
+                }
+            }
+        }
+        if (STORE && active) {
+#pragma unroll
+            for (int d = 0; d < NDW; d++)
+                po[d] = w[d];
+        }
+    }
+}
+
+template <int NDW, bool STORE>
+__global__ __launch_bounds__(64) void k3_rows(const uint8_t *__restrict__ frames, const uint8_t *__restrict__ mu,
+                                              const uint8_t *__restrict__ sigma6,
+                                              const abub_job *__restrict__ jobs, int W, int H,
+                                              int rows_per_chunk, int nchunks, uint32_t *__restrict__ hist,
+                                              uint8_t *__restrict__ img, const int32_t *__restrict__ cthr,
+                                              uint32_t *pairs, uint32_t pcap, uint32_t *pcount, uint32_t slot_base)
+{
+    constexpr int NP = 2 * NDW;
+    __shared__ uint32_t lh[256];
+    const int lane = threadIdx.x;
+    const int unit = blockIdx.x;
+    const int job = unit / nchunks;
+    const int chunk = unit - job * nchunks;
+    const abub_job jb = jobs[job];
+    const size_t P = (size_t)W * H;
+    const uint8_t *f = frames + (size_t)jb.cur * P;
+    const uint8_t *m = mu + (size_t)jb.model * P;
+    const uint8_t *sg = sigma6 + (size_t)jb.model * P;
+    const int nl = W / (4 * NDW);
+    const bool active = lane < nl;
+    const bool first_lane = lane == 0, last_lane = lane == nl - 1;
+    const int xoff = active ? lane * 4 * NDW : 0;
+    const int y0 = chunk * rows_per_chunk;
+    int y1 = y0 + rows_per_chunk;
+    if (y1 > H)
+        y1 = H;
+    const int T = y1 - y0 + 2; // input rows y0-1 .. y1 (reflected)
+
+    lh[lane] = 0;
+    lh[lane + 64] = 0;
+    lh[lane + 128] = 0;
+    lh[lane + 192] = 0;
+    __syncthreads();
+
+    uint32_t a0[NP], xp[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++)
+        a0[j] = xp[j] = 0;
+    uint8_t *obase = STORE ? img + (size_t)jb.out * P + xoff : nullptr;
+    Compact cp;
+    cp.pairs = cthr ? pairs : nullptr;
+    cp.count = pcount;
+    cp.cap = pcap;
+    cp.slot = jb.out + slot_base;
+    cp.thr = cthr ? cthr[jb.out] : 255;
+
+    Row3In<NDW> ring[2];
+    k3_load_row<NDW>(ring[0], f, m, sg, reflect101(y0 - 1, H), W, xoff);
+    for (int t = 0; t < T; t += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int tt = t + u;
+            if (tt < T) {
+                int tn = tt + 1 < T ? tt + 1 : T - 1;
+                k3_load_row<NDW>(ring[(u + 1) & 1], f, m, sg, reflect101(y0 - 1 + tn, H), W, xoff);
+                int y = y0 + tt - 2;
+                k3_row<NDW, STORE>(ring[u], a0, xp, tt >= 2, active, first_lane, last_lane, lh,
+                                   reinterpret_cast<uint32_t *>(obase + (ptrdiff_t)y * W), cp,
+                                   (uint32_t)(y * W + xoff));
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *gh = hist + (size_t)jb.out * 256;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t v = lh[lane + 64 * k];
+        if (v && (lane + 64 * k))
+            atomicAdd(&gh[lane + 64 * k], v);
+    }
+}
+
+template <int NDW>
+static void launch_k3_rows(const uint8_t *frames, const uint8_t *mu, const uint8_t *sigma6, const abub_job *jobs,
+                           int njobs, int W, int H, int R, int nchunks, uint32_t *hist, uint8_t *img,
+                           const CompactArgs &ca, hipStream_t st)
+{
+    dim3 grid((unsigned)njobs * nchunks), block(64);
+    if (img)
+        hipLaunchKernelGGL((k3_rows<NDW, true>), grid, block, 0, st, frames, mu, sigma6, jobs, W, H, R, nchunks,
+                           hist, img, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base);
+    else
+        hipLaunchKernelGGL((k3_rows<NDW, false>), grid, block, 0, st, frames, mu, sigma6, jobs, W, H, R, nchunks,
+                           hist, img, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base);
+}
+
+static int posttrig_impl(const uint8_t *frames, const uint8_t *mu, const uint8_t *sigma6, const abub_job *jobs,
+                         int njobs, int W, int H, uint32_t *hist, uint8_t *img, const CompactArgs &ca, void *stream);
+
 extern "C" int abub_posttrig_dev(const uint8_t *frames, const uint8_t *mu, const uint8_t *sigma6,
                                  const abub_job *jobs, int njobs, int W, int H, uint32_t *hist,
                                  uint8_t *img, void *stream)
+{
+    CompactArgs ca = {nullptr, nullptr, 0, nullptr, 0};
+    return posttrig_impl(frames, mu, sigma6, jobs, njobs, W, H, hist, img, ca, stream);
+}
+
+extern "C" int abub_posttrig_compact_dev(const uint8_t *frames, const uint8_t *mu, const uint8_t *sigma6,
+                                         const abub_job *jobs, int njobs, int W, int H, uint32_t *hist,
+                                         uint8_t *img, const int32_t *cthr, uint32_t *pairs, uint32_t cap,
+                                         uint32_t *count, uint32_t slot_base, void *stream)
+{
+    if (!cthr || !pairs || !count || cap == 0)
+        return set_err(ABUB_E_INVALID, "abub_posttrig_compact_dev: bad arguments");
+    CompactArgs ca = {cthr, pairs, cap, count, slot_base};
+    return posttrig_impl(frames, mu, sigma6, jobs, njobs, W, H, hist, img, ca, stream);
+}
+
+static int posttrig_impl(const uint8_t *frames, const uint8_t *mu, const uint8_t *sigma6, const abub_job *jobs,
+                         int njobs, int W, int H, uint32_t *hist, uint8_t *img, const CompactArgs &ca, void *stream)
 {
     if (!frames || !mu || !sigma6 || !jobs || !hist || W <= 0 || H <= 0 || njobs < 0)
         return set_err(ABUB_E_INVALID, "abub_posttrig_dev: bad arguments");
     if (njobs == 0)
         return ABUB_OK;
-    if (njobs > 65535)
-        return set_err(ABUB_E_INVALID, "abub_posttrig_dev: njobs > 65535");
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipMemsetAsync(hist, 0, (size_t)njobs * 256 * sizeof(uint32_t), st));
-    dim3 grid((W + G_TW - 1) / G_TW, (H + G_TH - 1) / G_TH, njobs), block(256);
-    hipLaunchKernelGGL(k3_generic, grid, block, 0, st, frames, mu, sigma6, jobs, W, H, hist, img);
+    int ndw = pick_ndw(W);
+    if (ndw) {
+        int R = njobs >= 64 ? (H + 7) / 8 : (njobs >= 8 ? (H + 31) / 32 : 16);
+        if (R < 8)
+            R = 8;
+        int nchunks = (H + R - 1) / R;
+        switch (ndw) {
+        case 1: launch_k3_rows<1>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
+        case 2: launch_k3_rows<2>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
+        case 3: launch_k3_rows<3>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
+        case 4: launch_k3_rows<4>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
+        case 5: launch_k3_rows<5>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
+        case 6: launch_k3_rows<6>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
+        case 7: launch_k3_rows<7>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
+        default: launch_k3_rows<8>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
+        }
+    } else {
+        if (ca.cthr)
+            return set_err(ABUB_E_INVALID, "fused compaction needs the fast path (W % 4 == 0, W <= 2048)");
+        if (njobs > 65535)
+            return set_err(ABUB_E_INVALID, "abub_posttrig_dev: njobs > 65535");
+        dim3 grid((W + G_TW - 1) / G_TW, (H + G_TH - 1) / G_TH, njobs), block(256);
+        hipLaunchKernelGGL(k3_generic, grid, block, 0, st, frames, mu, sigma6, jobs, W, H, hist, img);
+    }
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_hist_bin0, dim3(njobs), dim3(64), 0, st, hist, (uint32_t)((size_t)W * H));
     HIPCHK(hipGetLastError());
@@ -897,7 +1229,7 @@ __global__ __launch_bounds__(256) void k4_compact_pairs(const uint8_t *__restric
                     if (v > t) {
                         uint32_t pos = atomicAdd(count, 1u);
                         if (pos < cap) {
-                            pairs[2 * (size_t)pos] = k;
+                            pairs[2 * (size_t)pos] = k | ((uint32_t)v << 24);
                             pairs[2 * (size_t)pos + 1] = (uint32_t)(q * 16 + d * 4 + b);
                         }
                     }
@@ -909,7 +1241,7 @@ __global__ __launch_bounds__(256) void k4_compact_pairs(const uint8_t *__restric
             if ((int)im[i] > t) {
                 uint32_t pos = atomicAdd(count, 1u);
                 if (pos < cap) {
-                    pairs[2 * (size_t)pos] = k;
+                    pairs[2 * (size_t)pos] = k | ((uint32_t)im[i] << 24);
                     pairs[2 * (size_t)pos + 1] = (uint32_t)i;
                 }
             }
@@ -938,6 +1270,89 @@ extern "C" int abub_fg_compact_pairs_dev(const uint8_t *img, int nimg, int W, in
             return set_err(ABUB_E_INVALID, "abub_fg_compact_pairs_dev: nimg > 65535");
         hipLaunchKernelGGL(k4_compact_pairs, dim3(bx, n), dim3(256), 0, st, img, P, thr, pairs, cap, count);
     }
+    HIPCHK(hipGetLastError());
+    return ABUB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Group the shared candidate list by slot on the device (counting sort), so that the host receives
+// every image's pixels as one contiguous run: count per slot -> exclusive scan -> scatter.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pairs_count(const uint32_t *__restrict__ pairs,
+                                                     const uint32_t *__restrict__ count, uint32_t cap,
+                                                     uint32_t nslots, uint32_t *__restrict__ slotcount)
+{
+    uint32_t n = *count;
+    if (n > cap)
+        n = cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t s = pairs[2 * (size_t)i] & 0x00ffffffu;
+        if (s < nslots)
+            atomicAdd(&slotcount[s], 1u);
+    }
+}
+
+// single block: offsets[s] = sum_{t<s} slotcount[t], offsets[nslots] = total; cursor = offsets
+__global__ __launch_bounds__(1024) void k_pairs_scan(const uint32_t *__restrict__ slotcount, uint32_t nslots,
+                                                     uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (nslots + 1023) / 1024;
+    const uint32_t lo = t * per, hi = lo + per < nslots ? lo + per : nslots;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++)
+        sum += slotcount[i];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        uint32_t v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (uint32_t i = lo; i < hi; i++) {
+        offsets[i] = run;
+        cursor[i] = run;
+        run += slotcount[i];
+    }
+    if (t == 1023)
+        offsets[nslots] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void k_pairs_scatter(const uint32_t *__restrict__ pairs,
+                                                       const uint32_t *__restrict__ count, uint32_t cap,
+                                                       uint32_t nslots, uint32_t *__restrict__ cursor,
+                                                       uint32_t *__restrict__ idx_out, uint8_t *__restrict__ val_out)
+{
+    uint32_t n = *count;
+    if (n > cap)
+        n = cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t w0 = pairs[2 * (size_t)i], w1 = pairs[2 * (size_t)i + 1];
+        uint32_t s = w0 & 0x00ffffffu;
+        if (s < nslots) {
+            uint32_t pos = atomicAdd(&cursor[s], 1u);
+            idx_out[pos] = w1;
+            val_out[pos] = (uint8_t)(w0 >> 24);
+        }
+    }
+}
+
+extern "C" int abub_pairs_group_dev(const uint32_t *pairs, const uint32_t *count, uint32_t cap, int nslots,
+                                    uint32_t *scratch /* [2*nslots] */, uint32_t *offsets /* [nslots+1] */,
+                                    uint32_t *idx_out /* [cap] */, uint8_t *val_out /* [cap] */, void *stream)
+{
+    if (!pairs || !count || !scratch || !offsets || !idx_out || !val_out || nslots <= 0 || cap == 0)
+        return set_err(ABUB_E_INVALID, "abub_pairs_group_dev: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t *slotcount = scratch, *cursor = scratch + nslots;
+    HIPCHK(hipMemsetAsync(slotcount, 0, (size_t)nslots * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_pairs_count, dim3(512), dim3(256), 0, st, pairs, count, cap, (uint32_t)nslots, slotcount);
+    hipLaunchKernelGGL(k_pairs_scan, dim3(1), dim3(1024), 0, st, slotcount, (uint32_t)nslots, offsets, cursor);
+    hipLaunchKernelGGL(k_pairs_scatter, dim3(512), dim3(256), 0, st, pairs, count, cap, (uint32_t)nslots, cursor,
+                       idx_out, val_out);
     HIPCHK(hipGetLastError());
     return ABUB_OK;
 }

@@ -253,9 +253,10 @@ class Pipeline:
             raise RuntimeError("pipeline: " + lib().abh_pipe_error().decode())
 
     def timing(self):
-        out = (C.c_double * 5)()
+        out = (C.c_double * 9)()
         rounds = lib().abh_pipe_timing(self._h, out)
-        return dict(zip(("stage1_ms", "stage2_ms", "stage3_ms", "stage4_ms", "total_ms"), list(out)), rounds=rounds)
+        return dict(zip(("stage1_ms", "stage2_ms", "stage3_ms", "stage4_ms", "total_ms", "s3_gpu_ms", "s3_list_ms",
+                         "s3_bucket_ms", "pairs"), list(out)), rounds=rounds)
 
     def result(self, s):
         L = lib()

@@ -49,7 +49,9 @@ struct PlannedImage {
     int slot; // index into the image / histogram slabs of this round
     int tozero;
     int thr;
-    std::vector<uint32_t> fg;
+    const uint32_t *fg = nullptr; // raster indices of the candidate pixels (value > tozero), grouped on the GPU
+    const uint8_t *fgv = nullptr; // their values: the Otsu cut is applied on the host
+    uint32_t nfg = 0;
 };
 
 // EventData served from the pipeline's batched results
@@ -88,7 +90,11 @@ public:
     {
         if (cur < 0 || planned[cur].thr != thr)
             throw std::runtime_error("BatchEventData::foreground: threshold differs from the planned one");
-        idx.swap(planned[cur].fg);
+        const PlannedImage &p = planned[cur];
+        idx.clear();
+        for (uint32_t k = 0; k < p.nfg; ++k)
+            if ((int)p.fgv[k] > thr)
+                idx.push_back(p.fg[k]);
     }
 };
 
@@ -155,6 +161,10 @@ public:
     int32_t *d_thr = nullptr;      // [S*11]
     uint32_t *d_pairs = nullptr;   // [cap][2]
     uint32_t *d_count = nullptr;
+    uint32_t *d_gscratch = nullptr, *d_goff = nullptr, *d_gidx = nullptr; // grouped list
+    uint8_t *d_gval = nullptr;
+    uint32_t *h_goff = nullptr, *h_gidx = nullptr;
+    uint8_t *h_gval = nullptr;
     uint32_t pairCap = 0;
     // pinned host
     uint32_t *h_hist1 = nullptr, *h_hist3 = nullptr, *h_pairs = nullptr, *h_count = nullptr;
@@ -167,6 +177,7 @@ public:
     MemParser parser;
     double tms[8] = {0};
     int rounds = 0;
+    uint32_t lastPairs = 0;
 
     RunPipeline(int device_, int W_, int H_, int F_, int E_, int C_, const int *tss_, int nthreads_, const char *maskdir)
         : device(device_), W(W_), H(H_), F(F_), E(E_), C(C_), S(E_ * C_), nthreads(nthreads_), P((size_t)W_ * H_),
@@ -185,6 +196,13 @@ public:
         HIPOK(hipMalloc((void **)&d_thr, n3 * sizeof(int32_t)));
         HIPOK(hipMalloc((void **)&d_pairs, (size_t)pairCap * 8));
         HIPOK(hipMalloc((void **)&d_count, sizeof(uint32_t)));
+        HIPOK(hipMalloc((void **)&d_gscratch, 2 * n3 * sizeof(uint32_t)));
+        HIPOK(hipMalloc((void **)&d_goff, (n3 + 1) * sizeof(uint32_t)));
+        HIPOK(hipMalloc((void **)&d_gidx, (size_t)pairCap * 4));
+        HIPOK(hipMalloc((void **)&d_gval, (size_t)pairCap));
+        HIPOK(hipHostMalloc((void **)&h_goff, (n3 + 1) * sizeof(uint32_t), hipHostMallocDefault));
+        HIPOK(hipHostMalloc((void **)&h_gidx, (size_t)pairCap * 4, hipHostMallocDefault));
+        HIPOK(hipHostMalloc((void **)&h_gval, (size_t)pairCap, hipHostMallocDefault));
         HIPOK(hipHostMalloc((void **)&h_hist1, n1 * 1024, hipHostMallocDefault));
         HIPOK(hipHostMalloc((void **)&h_hist3, n3 * 1024, hipHostMallocDefault));
         HIPOK(hipHostMalloc((void **)&h_pairs, (size_t)pairCap * 8, hipHostMallocDefault));
@@ -230,6 +248,13 @@ public:
         (void)hipFree(d_thr);
         (void)hipFree(d_pairs);
         (void)hipFree(d_count);
+        (void)hipFree(d_gscratch);
+        (void)hipFree(d_goff);
+        (void)hipFree(d_gidx);
+        (void)hipFree(d_gval);
+        (void)hipHostFree(h_goff);
+        (void)hipHostFree(h_gidx);
+        (void)hipHostFree(h_gval);
         (void)hipHostFree(h_hist1);
         (void)hipHostFree(h_hist3);
         (void)hipHostFree(h_pairs);
@@ -393,47 +418,64 @@ private:
             }
         }
         const int nimg = nd + np;
-        HIPOK(hipMemcpyAsync(d_jobs3, h_jobs3, (size_t)nimg * sizeof(abub_job), hipMemcpyHostToDevice, stream));
-        check(abub_diff_hist_dev(d_frames, d_sigma6, d_jobs3, nd, W, H, d_hist3, d_img, 0, stream), "stage3 K2 store");
-        if (np > 0)
-            check(abub_posttrig_dev(d_frames, d_mu, d_sigma6, d_jobs3 + nd, np, W, H, d_hist3 + (size_t)nd * 256,
-                                    d_img + (size_t)nd * P, stream),
-                  "stage3 K3");
-        HIPOK(hipMemcpyAsync(h_hist3, d_hist3, (size_t)nimg * 1024, hipMemcpyDeviceToHost, stream));
-        HIPOK(hipStreamSynchronize(stream));
-        // thresholds (TOZERO + Otsu) on the host from the histograms
+        double ta = nowMs();
         std::vector<PlannedImage *> bySlot((size_t)nimg);
         for (int s : loc) {
             stacks[s].data.roundHists = h_hist3;
-            for (PlannedImage &p : stacks[s].data.planned)
+            for (PlannedImage &p : stacks[s].data.planned) {
                 bySlot[p.slot] = &p;
+                h_thr[p.slot] = p.tozero; // candidate cut = TOZERO threshold, known before the launch
+            }
         }
-        parallelFor(nimg, nthreads, [&](int k) {
-            PlannedImage *p = bySlot[k];
-            p->thr = binarizeThresholdFromHist(h_hist3 + (size_t)k * 256, P, p->tozero);
-            h_thr[k] = p->thr;
-        });
+        HIPOK(hipMemcpyAsync(d_jobs3, h_jobs3, (size_t)nimg * sizeof(abub_job), hipMemcpyHostToDevice, stream));
         HIPOK(hipMemcpyAsync(d_thr, h_thr, (size_t)nimg * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-        check(abub_fg_compact_pairs_dev(d_img, nimg, W, H, d_thr, d_pairs, pairCap, d_count, stream), "stage3 K4");
+        HIPOK(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
+        const bool fused = abub_fast_path(W) != 0;
+        if (fused) {
+            // images are never materialised: histogram + candidate list come out of the same pass
+            check(abub_diff_hist_compact_dev(d_frames, d_sigma6, d_jobs3, nd, W, H, d_hist3, nullptr, d_thr, d_pairs,
+                                             pairCap, d_count, 0, stream),
+                  "stage3 K2 compact");
+            if (np > 0)
+                check(abub_posttrig_compact_dev(d_frames, d_mu, d_sigma6, d_jobs3 + nd, np, W, H,
+                                                d_hist3 + (size_t)nd * 256, nullptr, d_thr + nd, d_pairs, pairCap,
+                                                d_count, (uint32_t)nd, stream),
+                      "stage3 K3 compact");
+        } else {
+            check(abub_diff_hist_dev(d_frames, d_sigma6, d_jobs3, nd, W, H, d_hist3, d_img, 0, stream), "stage3 K2 store");
+            if (np > 0)
+                check(abub_posttrig_dev(d_frames, d_mu, d_sigma6, d_jobs3 + nd, np, W, H, d_hist3 + (size_t)nd * 256,
+                                        d_img + (size_t)nd * P, stream),
+                      "stage3 K3");
+            check(abub_fg_compact_pairs_dev(d_img, nimg, W, H, d_thr, d_pairs, pairCap, d_count, stream), "stage3 K4");
+        }
+        // group the list by image on the device; the host gets contiguous runs and never re-buckets
+        check(abub_pairs_group_dev(d_pairs, d_count, pairCap, nimg, d_gscratch, d_goff, d_gidx, d_gval, stream),
+              "stage3 group");
+        HIPOK(hipMemcpyAsync(h_hist3, d_hist3, (size_t)nimg * 1024, hipMemcpyDeviceToHost, stream));
         HIPOK(hipMemcpyAsync(h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIPOK(hipMemcpyAsync(h_goff, d_goff, (size_t)(nimg + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIPOK(hipStreamSynchronize(stream));
+        tms[5] += nowMs() - ta; // launches + kernels + hist/count D2H
+        ta = nowMs();
         const uint32_t cnt = *h_count;
+        lastPairs = cnt;
         if (cnt > pairCap)
             throw std::runtime_error("RunPipeline: foreground list overflow (dense foreground in too many images)");
         if (cnt) {
-            HIPOK(hipMemcpyAsync(h_pairs, d_pairs, (size_t)cnt * 8, hipMemcpyDeviceToHost, stream));
-            HIPOK(hipStreamSynchronize(stream));
+            HIPOK(hipMemcpyAsync(h_gidx, d_gidx, (size_t)cnt * 4, hipMemcpyDeviceToHost, stream));
+            HIPOK(hipMemcpyAsync(h_gval, d_gval, (size_t)cnt, hipMemcpyDeviceToHost, stream));
         }
-        // bucket by image
-        std::vector<uint32_t> n((size_t)nimg, 0);
-        for (uint32_t k = 0; k < cnt; ++k)
-            n[h_pairs[2 * (size_t)k]]++;
-        for (int k = 0; k < nimg; ++k) {
-            bySlot[k]->fg.clear();
-            bySlot[k]->fg.reserve(n[k]);
-        }
-        for (uint32_t k = 0; k < cnt; ++k)
-            bySlot[h_pairs[2 * (size_t)k]]->fg.push_back(h_pairs[2 * (size_t)k + 1]);
+        // thresholds (TOZERO + Otsu) on the host from the histograms, while the list travels
+        parallelFor(nimg, nthreads, [&](int k) {
+            PlannedImage *p = bySlot[k];
+            p->thr = binarizeThresholdFromHist(h_hist3 + (size_t)k * 256, P, p->tozero);
+            p->fg = h_gidx + h_goff[k];
+            p->fgv = h_gval + h_goff[k];
+            p->nfg = h_goff[k + 1] - h_goff[k];
+        });
+        HIPOK(hipStreamSynchronize(stream));
+        tms[6] += nowMs() - ta; // list D2H (+ thresholds)
     }
 
     // AnyCamAnalysis body from LocalizeOMatic on (AutoBubStart3.cpp:94-110)
@@ -523,8 +565,9 @@ const char *abh_pipe_stack_error(void *p, int s) { return ((abub::RunPipeline *)
 int abh_pipe_timing(void *p, double *out)
 {
     abub::RunPipeline *r = (abub::RunPipeline *)p;
-    for (int k = 0; k < 5; ++k)
+    for (int k = 0; k < 8; ++k)
         out[k] = r->tms[k];
+    out[8] = r->lastPairs;
     return r->rounds;
 }
 }

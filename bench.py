@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--train-events", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--threads", type=int, default=16, help="host threads of the per-event state machines")
     return ap.parse_args()
 
 
@@ -88,31 +89,31 @@ def main():
     torch.cuda.synchronize()
     gen_s = time.time() - t0
 
-    # ---- the step ------------------------------------------------------------------------------
-    jobs = hip.stack_jobs(S, F, 1, F - 1, 2, C, dev)
-    njobs = jobs.shape[0]
-    hist = torch.empty((njobs, 256), dtype=torch.int32, device=dev)
-    hist_h = torch.empty((njobs, 256), dtype=torch.int32).pin_memory()
-    k2_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-             for _ in range(args.steps)]
+    # ---- the step: end-to-end detect of the whole run (host/pipeline.cpp) -------------------------
+    from autobub3hs_amd import host
 
-    def step(k=None):
-        if k is not None:
-            k2_ev[k][0].record()
-        hip.diff_hist(slab, s6_d, jobs, W, H, store=False, hist=hist)
-        if k is not None:
-            k2_ev[k][1].record()
-        hist_h.copy_(hist, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+    tss = [2 * min(args.train_events, E)] * C
+    pipe = host.Pipeline(local, W, H, F, E, C, tss, nthreads=args.threads)
+    stream = torch.cuda.current_stream().cuda_stream
+    njobs = S * (F - 1)
+
+    def step():
+        pipe.run(slab, mu_d, s6_d, stream)
+        return pipe.timing()
 
     for _ in range(args.warmup):
         step()
+    fingerprint = pipe.summary()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    stage = {"stage1_ms": 0.0, "stage2_ms": 0.0, "stage3_ms": 0.0, "stage4_ms": 0.0, "total_ms": 0.0, "s3_gpu_ms": 0.0,
+             "s3_list_ms": 0.0, "s3_bucket_ms": 0.0, "pairs": 0.0, "rounds": 0}
     for k in range(args.steps):
-        step(k)
+        tm = step()
+        for kk in stage:
+            stage[kk] += tm[kk]
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -121,10 +122,26 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    assert pipe.summary() == fingerprint, "results changed between steps"
+    n_trig = sum(1 for r in fingerprint if r[0] == 0)
+    n_bub = sum(r[2] for r in fingerprint)
+
+    # ---- dominant kernel alone, HIP events on the launch stream (roofline object) ---------------
+    jobs = hip.stack_jobs(S, F, 1, F - 1, 2, C, dev)
+    hist = torch.empty((njobs, 256), dtype=torch.int32, device=dev)
+    kreps = max(3, min(10, args.steps))
+    hip.diff_hist(slab, s6_d, jobs, W, H, store=False, hist=hist)
+    k2_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(kreps)]
+    for a_, b_ in k2_ev:
+        a_.record()
+        hip.diff_hist(slab, s6_d, jobs, W, H, store=False, hist=hist)
+        b_.record()
+    torch.cuda.synchronize()
+    k2_ms = sum(a_.elapsed_time(b_) for a_, b_ in k2_ev) / kreps
+    hist_h = hist.cpu()
 
     frames_per_step = S * F * world
     value = frames_per_step * args.steps / dt
-    k2_ms = sum(a.elapsed_time(b) for a, b in k2_ev) / max(1, args.steps)
     alg_bytes = 3.0 * P * njobs  # trigger-only mode: read cur, ref, sigma; D not materialised
     achieved = alg_bytes / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
 
@@ -142,14 +159,17 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "config": {
-            "workload": f"synthetic 40l-19-like run: {E} events x {C} cams x {F} frames {W}x{H} u8 per GPU, HBM-resident",
-            "stage": "trigger search (K2 fused ProcessFrame+hist, all stacks in one launch) + histogram D2H",
+            "workload": f"synthetic 40l-19-like run: {E} events x {C} cams x {F} frames {W}x{H} u8 per GPU, HBM-resident; "
+                        "per step: trigger search over every frame, genesis localisation, <=10-frame tracking, per-bubble records",
             "events_per_gpu": E, "cams": C, "frames_per_stack": F, "width": W, "height": H,
             "parallelism": f"events sharded over {world} GPU(s), no collective",
+            "host_threads": args.threads,
+            "triggered_stacks": n_trig, "bubbles": n_bub,
+            "stage_ms": {k: round(v / args.steps, 3) for k, v in stage.items()},
             "gen_seconds": round(gen_s, 1),
         },
         "roofline": {
-            "kernel": "k2_rows<5,false> (fused ProcessFrame + 256-bin histogram, trigger-only mode: 3*W*H B/job)",
+            "kernel": "k2_rows<5,false,1> (fused ProcessFrame + 256-bin histogram, trigger-only mode: 3*W*H B/job)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
             "ms_per_launch": k2_ms, "jobs_per_launch": njobs,
@@ -157,27 +177,41 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # CPU baseline = the oracle's whole detect path (AnyCamAnalysis restatement) on a bounded sample
+        # of the same stacks, 1 core.  It doubles as a full-size parity check of the GPU results.
         from oracle import pyoracle as orc
 
         orc.build()
-        sg0 = sg_d[0].cpu().numpy()
-        done, tcpu = 0, 0.0
-        s = 0
-        while tcpu < args.cpu_seconds and s < S:
-            st = slab[s].cpu().numpy()
-            c = s % C
+        done, tcpu, nstk = 0, 0.0, 0
+        s_i = 0
+        mu_h = mu_d.cpu().numpy()
+        sg_h = sg_d.cpu().numpy()
+        while tcpu < args.cpu_seconds and s_i < S:
+            st = slab[s_i].cpu().numpy()
+            c = s_i % C
             tc = time.perf_counter()
-            _, hh = orc.bench_trigger_pass(st, sg_d[c].cpu().numpy(), 2, 1, F - 1, want_hists=True)
+            a = orc.Analyzer(st, mu_h[c], sg_h[c], tss[c])
+            staged_r, state_r, bub_r = a.any_cam_analysis()
             tcpu += time.perf_counter() - tc
-            # the CPU sample doubles as a full-size parity check of the GPU histograms
-            if not np.array_equal(hh, hist_h[s * (F - 1):(s + 1) * (F - 1)].numpy().astype(np.uint32)):
+            a.close()
+            staged, state, bub, err = pipe.result(s_i)
+            same = (staged, state) == (staged_r, state_r) and len(bub) == len(bub_r) and all(
+                [tuple(d[k] for k in "xywh") for d in b["desc"]] == [tuple(d[k] for k in "xywh") for d in r["desc"]]
+                for b, r in zip(bub, bub_r))
+            if not same:
+                raise SystemExit(f"bench.py: GPU result of stack {s_i} differs from the CPU oracle: "
+                                 f"{(staged, state)} vs {(staged_r, state_r)} {err}")
+            # and the trigger-pass histograms of that stack, bit for bit
+            _, hh = orc.bench_trigger_pass(st, sg_h[c], 2, 1, F - 1, want_hists=True)
+            if not np.array_equal(hh, hist_h[s_i * (F - 1):(s_i + 1) * (F - 1)].numpy().astype(np.uint32)):
                 raise SystemExit("bench.py: GPU histograms differ from the CPU oracle on the sampled stack")
             done += F
-            s += max(1, S // 8)
+            nstk += 1
+            s_i += max(1, S // 8)
         out["cpu_baseline"] = {
             "value": done / tcpu, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{done} frames ({done // F} stacks of {F}) of the same workload, ProcessFrame+calcHist "
-                      f"restatement (oracle/abub_oracle.c, gcc -O2), {tcpu:.1f} s on 1 core of {os.cpu_count()}",
+            "sample": f"{nstk} stacks ({done} frames) of the same workload through the oracle's end-to-end detect "
+                      f"(oracle/abub_oracle.c, gcc -O2, results identical to the GPU's), {tcpu:.1f} s on 1 core of {os.cpu_count()}",
         }
     if rank == 0:
         print(json.dumps(out))

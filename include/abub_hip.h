@@ -101,8 +101,32 @@ int abub_posttrig_dev(const uint8_t *frames, const uint8_t *mu, const uint8_t *s
 int abub_fg_compact_dev(const uint8_t *img, int nimg, int W, int H, const int32_t *thr,
                         uint32_t *idx, int cap, uint32_t *count, void *stream);
 
-/* K4, batched form: one shared output list of (image, raster index) pairs for all nimg images,
- * pairs[2*k] = image number, pairs[2*k+1] = y*W+x (unordered); *count = true total (may exceed cap). */
+/* Fused forms for the batched run pipeline: K2 / K3 as above, and every output pixel with value
+ * > cthr[slot] is appended to ONE shared list, pairs[2k] = slot | value << 24, pairs[2k+1] = y*W+x
+ * with slot = slot_base + job.out; cthr is indexed by job.out
+ * (unordered; *count = true total, may exceed cap; count must be zeroed by the caller).  With the
+ * list the images need not be materialised (diff / img may be NULL): cthr = the TOZERO threshold is
+ * known before the launch, the final Otsu cut is applied to the listed values on the host.
+ * Fast path only (abub_fast_path(W) != 0). */
+int abub_fast_path(int W);
+int abub_diff_hist_compact_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs, int njobs,
+                               int W, int H, uint32_t *hist, uint8_t *diff, const int32_t *cthr,
+                               uint32_t *pairs, uint32_t cap, uint32_t *count, uint32_t slot_base,
+                               void *stream);
+int abub_posttrig_compact_dev(const uint8_t *frames, const uint8_t *mu, const uint8_t *sigma6,
+                              const abub_job *jobs, int njobs, int W, int H, uint32_t *hist, uint8_t *img,
+                              const int32_t *cthr, uint32_t *pairs, uint32_t cap, uint32_t *count,
+                              uint32_t slot_base, void *stream);
+
+/* Group such a list by slot on the device (counting sort): offsets[s] .. offsets[s+1] delimit slot s
+ * in idx_out / val_out (raster index, value); offsets[nslots] = total (<= cap).  `count` is read on the
+ * device, no host synchronisation needed between the producing launches and this call. */
+int abub_pairs_group_dev(const uint32_t *pairs, const uint32_t *count, uint32_t cap, int nslots,
+                         uint32_t *scratch /* [2*nslots] */, uint32_t *offsets /* [nslots+1] */,
+                         uint32_t *idx_out /* [cap] */, uint8_t *val_out /* [cap] */, void *stream);
+
+/* K4, batched form: one shared output list for all nimg images, pairs[2*k] = image | value << 24,
+ * pairs[2*k+1] = y*W+x (unordered); *count = true total (may exceed cap). */
 int abub_fg_compact_pairs_dev(const uint8_t *img, int nimg, int W, int H, const int32_t *thr,
                               uint32_t *pairs, uint32_t cap, uint32_t *count, void *stream);
 

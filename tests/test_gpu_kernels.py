@@ -131,7 +131,7 @@ def test_k1b_pair_hist_parity(oracle):
         assert np.array_equal(h[o].astype(np.uint32), oracle.hist256(d))
 
 
-@pytest.mark.parametrize("H,W", [(40, 56), (3, 3), (17, 5), (64, 1280), (1, 7)])
+@pytest.mark.parametrize("H,W", [(40, 56), (3, 3), (17, 5), (64, 1280), (1, 7), (50, 1680), (9, 2048), (33, 768), (2, 512), (1, 256)])
 def test_k3_posttrig_parity(oracle, H, W):
     rs = np.random.RandomState(H + W)
     fr = rnd_frames(rs, 3, H, W, amp=25)
@@ -187,3 +187,56 @@ def test_full_size_properties():
     nz = D[spec.t0 - 1].nonzero()
     assert len(nz) > 0
     assert abs(nz[:, 0].float().mean().item() - 512) < 1.0 and abs(nz[:, 1].float().mean().item() - 640) < 1.0
+
+
+def test_fused_compaction_lists(oracle):
+    """K2 / K3 with the fused candidate list: entries = exactly the pixels with value > cthr, with their
+    values, tagged slot_base + job.out; histograms unchanged; images not materialised."""
+    import ctypes as C
+
+    from autobub3hs_amd import _lib
+
+    W, H = 1280, 96
+    rs = np.random.RandomState(77)
+    fr = rnd_frames(rs, 5, H, W, amp=14)
+    fr[3, 40:60, 600:640] = np.clip(fr[3, 40:60, 600:640].astype(int) + 70, 0, 255)
+    mu = fr[0:1].copy()
+    sg = rs.randint(0, 2, (1, H, W)).astype(np.uint8)
+    f_d = torch.from_numpy(fr).to(DEV)
+    mu_d = torch.from_numpy(mu).to(DEV)
+    s6 = hip.sigma6(torch.from_numpy(sg).to(DEV))
+    L = _lib.lib()
+    cap = 1 << 20
+    pairs = torch.zeros((cap, 2), dtype=torch.int32, device=DEV)
+    count = torch.zeros((1,), dtype=torch.int32, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    # K2: two jobs, slots 0,1
+    jobs2 = hip.make_jobs([(3, 1, 0, 0), (4, 2, 0, 1)], DEV)
+    cthr2 = torch.tensor([2, 3], dtype=torch.int32, device=DEV)
+    hist2 = torch.empty((2, 256), dtype=torch.int32, device=DEV)
+    _lib.check(L.abub_diff_hist_compact_dev(f_d.data_ptr(), s6.data_ptr(), jobs2.data_ptr(), 2, W, H, hist2.data_ptr(),
+                                            None, cthr2.data_ptr(), pairs.data_ptr(), cap, count.data_ptr(), 0, st))
+    # K3: two jobs appended to the same list with slot_base 2
+    jobs3 = hip.make_jobs([(3, 0, 0, 0), (4, 0, 0, 1)], DEV)
+    cthr3 = torch.tensor([3, 3], dtype=torch.int32, device=DEV)
+    hist3 = torch.empty((2, 256), dtype=torch.int32, device=DEV)
+    _lib.check(L.abub_posttrig_compact_dev(f_d.data_ptr(), mu_d.data_ptr(), s6.data_ptr(), jobs3.data_ptr(), 2, W, H,
+                                           hist3.data_ptr(), None, cthr3.data_ptr(), pairs.data_ptr(), cap,
+                                           count.data_ptr(), 2, st))
+    torch.cuda.synchronize()
+    n = int(count.item())
+    pr = pairs[:n].cpu().numpy().astype(np.uint32)
+    imgs = [oracle.process_frame(fr[3], fr[1], sg[0]), oracle.process_frame(fr[4], fr[2], sg[0]),
+            oracle.posttrig_frame(fr[3], mu[0], sg[0]), oracle.posttrig_frame(fr[4], mu[0], sg[0])]
+    thr = [2, 3, 3, 3]
+    total = 0
+    for slot in range(4):
+        sel = pr[(pr[:, 0] & 0xFFFFFF) == slot]
+        exp = np.flatnonzero(imgs[slot].ravel() > thr[slot])
+        order = np.argsort(sel[:, 1])
+        assert np.array_equal(sel[order, 1], exp), slot
+        assert np.array_equal((sel[order, 0] >> 24).astype(np.uint8), imgs[slot].ravel()[exp])
+        total += len(exp)
+    assert total == n and n > 100
+    assert np.array_equal(hist2.cpu().numpy().astype(np.uint32), np.stack([oracle.hist256(imgs[0]), oracle.hist256(imgs[1])]))
+    assert np.array_equal(hist3.cpu().numpy().astype(np.uint32), np.stack([oracle.hist256(imgs[2]), oracle.hist256(imgs[3])]))

@@ -209,3 +209,10 @@ def test_binarize(oracle):
     assert m[12, 12] == 255 and m[6, 6] == 0 and m.sum() == 25 * 255
     m2, _ = oracle.binarize(np.zeros((8, 8), np.uint8), 3)
     assert not m2.any()
+
+
+def test_div9_multiply_shift_used_by_k3():
+    # the fast post-trigger kernel computes (S+4)/9 as ((S+4)*7282)>>16 on 24-bit multipliers
+    S = np.arange(0, 9 * 255 + 1, dtype=np.int64)
+    assert np.array_equal(((S + 4) * 7282) >> 16, (S + 4) // 9)
+    assert int(((S + 4) * 7282).max()) < (1 << 24)
