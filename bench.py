@@ -44,7 +44,7 @@ def main():
     import numpy as np
     import torch
 
-    from autobub3hs_amd import hip, synth
+    from autobub3hs_amd import hip, shard, synth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -64,13 +64,14 @@ def main():
     P = W * H
     S = E * C  # stacks on this rank
 
-    # ---- synthetic run, generated straight into HBM (rank r owns events r*E .. r*E+E-1) ----------
+    # ---- synthetic run, generated straight into HBM (rank r owns events r, r+N, r+2N, ...) ----------
     t0 = time.time()
     slab = torch.empty((S, F, H, W), dtype=torch.uint8, device=dev)
     specs = []
     bgs = [synth.background(W, H, synth.BASE_SEED + c, "torch", dev) for c in range(C)]
+    ev_ids = shard.global_event_ids(E, rank, world)  # round-robin over ranks, like schedule(static,1)
     for e in range(E):
-        ev = rank * E + e
+        ev = ev_ids[e]
         for c in range(C):
             spec = synth.random_spec(W, H, F, ev, c, p_second=0.2)
             specs.append(spec)
@@ -117,11 +118,7 @@ def main():
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
-    dt = time.perf_counter() - t1
-    if dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = shard.max_over_ranks(time.perf_counter() - t1, dev)
     assert pipe.summary() == fingerprint, "results changed between steps"
     n_trig = sum(1 for r in fingerprint if r[0] == 0)
     n_bub = sum(r[2] for r in fingerprint)
