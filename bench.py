@@ -141,6 +141,18 @@ def main():
     value = frames_per_step * args.steps / dt
     alg_bytes = 3.0 * P * njobs  # trigger-only mode: read cur, ref, sigma; D not materialised
     achieved = alg_bytes / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
+    # HBM traffic of this kernel from rocprofv3 PMC passes (tools/prof_k2.sh: FETCH_SIZE x2 + WRITE_SIZE, separate
+    # --pmc runs on the native microbench of the same kernel and frame size), scaled per job; null if not measured
+    traffic, traffic_src = None, None
+    for cand in sorted((os.path.join(ROOT, "profiles", d, "k2_hist_pmc_summary.json")
+                        for d in os.listdir(os.path.join(ROOT, "profiles"))
+                        if os.path.isdir(os.path.join(ROOT, "profiles", d))), reverse=True):
+        if os.path.exists(cand):
+            pm = json.load(open(cand))
+            if pm["micro"]["W"] == W and pm["micro"]["H"] == H:
+                traffic = pm["hbm_bytes_per_job"] * njobs
+                traffic_src = os.path.relpath(cand, ROOT)
+                break
 
     out = {
         "metric": "frames/s end-to-end detect @1280x1024 8-bit",
@@ -168,7 +180,8 @@ def main():
         "roofline": {
             "kernel": "k2_rows<5,false,1> (fused ProcessFrame + 256-bin histogram, trigger-only mode: 3*W*H B/job)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
             "ms_per_launch": k2_ms, "jobs_per_launch": njobs,
         },
     }
@@ -204,7 +217,7 @@ def main():
                 raise SystemExit("bench.py: GPU histograms differ from the CPU oracle on the sampled stack")
             done += F
             nstk += 1
-            s_i += max(1, S // 8)
+            s_i += max(1, S // 24)
         out["cpu_baseline"] = {
             "value": done / tcpu, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"{nstk} stacks ({done} frames) of the same workload through the oracle's end-to-end detect "
