@@ -91,12 +91,23 @@ __device__ __forceinline__ uint32_t pk_absdiff(uint32_t a, uint32_t b)
     s16x2 d = x - y, e = y - x;
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(d, e));
 }
-// two u16 lanes: a*6 + b  (v_pk_mad_u16)
-__device__ __forceinline__ uint32_t pk_mad6(uint32_t a, uint32_t b)
+// two u16 lanes: a*K + b  (v_pk_mad_u16 with an inline constant)
+template <int K>
+__device__ __forceinline__ uint32_t pk_madk(uint32_t a, uint32_t b)
 {
     u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
-    u16x2 six = {6, 6};
-    return __builtin_bit_cast(uint32_t, (u16x2)(x * six + y));
+    u16x2 k = {K, K};
+    return __builtin_bit_cast(uint32_t, (u16x2)(x * k + y));
+}
+
+// (a << 2) + b in one VALU op.  Written as asm because the compiler would CSE the shift of two such
+// expressions sharing `a` into shift + 2 adds (3 ops instead of 2).  No u16 lane overflows into its
+// neighbour here (all lanes <= 65408 after the add), so the 32-bit form is exact for both lanes.
+__device__ __forceinline__ uint32_t lshl2_add(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 // bytes (b0,b1) / (b2,b3) of a dword widened to two u16 lanes  (v_perm_b32)
@@ -260,16 +271,22 @@ __device__ __forceinline__ void compact_put(const Compact &cp, uint32_t &pos, ui
 }
 
 // persistent per-wave state of the vertical pass: four in-place accumulators per u16 pair and plane
-// out = a0 + X ; a0 = a1 + 4X ; a1 = a2 + 6X ; a2 = xp + 4X ; xp = X
+// out = a0 + X ; a0 = a1 + 4X ; a1 = a2 + 6X ; a2 = Xprev + 4X.  The previous row's X lives in a second
+// register set that alternates with the current one (K2Row), so nothing is copied at the loop back-edge.
 template <int NDW>
 struct K2Acc {
-    uint32_t pa0[2 * NDW], pa1[2 * NDW], pa2[2 * NDW], pxp[2 * NDW];
-    uint32_t na0[2 * NDW], na1[2 * NDW], na2[2 * NDW], nxp[2 * NDW];
+    uint32_t pa0[2 * NDW], pa1[2 * NDW], pa2[2 * NDW];
+    uint32_t na0[2 * NDW], na1[2 * NDW], na2[2 * NDW];
+};
+template <int NDW>
+struct K2Row {
+    uint32_t hp[2 * NDW], hn[2 * NDW]; // horizontally filtered row, both planes
 };
 
 // one input row -> one output row (valid once 5 rows went in)
 template <int NDW, bool STORE, bool COMPACT>
-__device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, bool emit, bool active,
+__device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, K2Row<NDW> &Hcur,
+                                       const K2Row<NDW> &Hprev, bool emit, bool active,
                                        bool first_lane, bool last_lane, uint32_t *lh,
                                        uint32_t *__restrict__ po, const Compact &cp, uint32_t pix0)
 {
@@ -302,7 +319,8 @@ __device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, bool
     Rp = last_lane ? reflRp : Rp;
     Rn = last_lane ? reflRn : Rn;
 
-    uint32_t Hp[NP], Hn[NP];
+    uint32_t(&Hp)[NP] = Hcur.hp;
+    uint32_t(&Hn)[NP] = Hcur.hn;
     {
         uint32_t am1p = __builtin_amdgcn_alignbit(Xp[0], Lp, 16); // (p[-1], p[0])
         uint32_t am1n = __builtin_amdgcn_alignbit(Xn[0], Ln, 16);
@@ -314,10 +332,8 @@ __device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, bool
             uint32_t ap1n = __builtin_amdgcn_alignbit(xp1n, Xn[j], 16);
             uint32_t sp = am1p + ap1p, sn = am1n + ap1n;
             uint32_t tp = xm1p + xp1p + 0x00080008u, tn = xm1n + xp1n + 0x00080008u;
-            tp = (sp << 2) + tp;
-            tn = (sn << 2) + tn;
-            Hp[j] = __umul24(Xp[j], 6u) + tp; // X <= 0x00ff00ff fits 24 bits
-            Hn[j] = __umul24(Xn[j], 6u) + tn;
+            Hp[j] = pk_madk<6>(Xp[j], (sp << 2) + tp); // every u16 lane <= 4088
+            Hn[j] = pk_madk<6>(Xn[j], (sn << 2) + tn);
             am1p = ap1p;
             am1n = ap1n;
         }
@@ -330,14 +346,12 @@ __device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, bool
     for (int j = 0; j < NP; j++) {
         uint32_t vp = A.pa0[j] + Hp[j];
         uint32_t vn = A.na0[j] + Hn[j];
-        A.pa0[j] = (Hp[j] << 2) + A.pa1[j];
-        A.na0[j] = (Hn[j] << 2) + A.na1[j];
-        A.pa1[j] = pk_mad6(Hp[j], A.pa2[j]);
-        A.na1[j] = pk_mad6(Hn[j], A.na2[j]);
-        A.pa2[j] = (Hp[j] << 2) + A.pxp[j];
-        A.na2[j] = (Hn[j] << 2) + A.nxp[j];
-        A.pxp[j] = Hp[j];
-        A.nxp[j] = Hn[j];
+        A.pa0[j] = lshl2_add(Hp[j], A.pa1[j]);
+        A.na0[j] = lshl2_add(Hn[j], A.na1[j]);
+        A.pa1[j] = pk_madk<6>(Hp[j], A.pa2[j]);
+        A.na1[j] = pk_madk<6>(Hn[j], A.na2[j]);
+        A.pa2[j] = lshl2_add(Hp[j], Hprev.hp[j]);
+        A.na2[j] = lshl2_add(Hn[j], Hprev.hn[j]);
         uint32_t rp = __builtin_amdgcn_perm(0u, vp, 0x0c030c01u); // byte1, byte3 of the u16 lanes
         uint32_t rn = __builtin_amdgcn_perm(0u, vn, 0x0c030c01u);
         Dp[j] = pk_absdiff(rp, rn);
@@ -427,7 +441,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER
     K2Acc<NDW> A;
 #pragma unroll
     for (int j = 0; j < NP; j++)
-        A.pa0[j] = A.pa1[j] = A.pa2[j] = A.pxp[j] = A.na0[j] = A.na1[j] = A.na2[j] = A.nxp[j] = 0;
+        A.pa0[j] = A.pa1[j] = A.pa2[j] = A.na0[j] = A.na1[j] = A.na2[j] = 0;
+    K2Row<NDW> HR[2];
+#pragma unroll
+    for (int j = 0; j < NP; j++)
+        HR[0].hp[j] = HR[0].hn[j] = HR[1].hp[j] = HR[1].hn[j] = 0;
 
     uint8_t *dbase = STORE ? diff + (size_t)jb.out * P + xoff : nullptr;
     Compact cp;
@@ -448,18 +466,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER
         int tk = k < T ? k : T - 1;
         k2_load_row<NDW>(ring[k], cur, ref, sg, reflect101(y0 - 2 + tk, H), W, xoff);
     }
-    for (int t = 0; t < T; t += U) {
+    // T is rounded up to a multiple of U: the (at most U-1) extra rows re-read the last input row and emit
+    // nothing, which keeps the unrolled body free of guards (no phi copies of the ring / accumulators)
+    const int Tpad = (T + U - 1) / U * U;
+    for (int t = 0; t < Tpad; t += U) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int tt = t + u;
-            if (tt < T) {
-                int tn = tt + PF < T ? tt + PF : T - 1;
-                k2_load_row<NDW>(ring[(u + PF) % RING], cur, ref, sg, reflect101(y0 - 2 + tn, H), W, xoff);
-                int y = y0 + tt - 4;
-                k2_row<NDW, STORE, COMPACT>(ring[u % RING], A, tt >= 4, active, first_lane, last_lane, lh,
-                                   reinterpret_cast<uint32_t *>(dbase + (ptrdiff_t)y * W), cp,
-                                   (uint32_t)(y * W + xoff));
-            }
+            int tn = tt + PF < T ? tt + PF : T - 1;
+            k2_load_row<NDW>(ring[(u + PF) % RING], cur, ref, sg, reflect101(y0 - 2 + tn, H), W, xoff);
+            int y = y0 + tt - 4;
+            k2_row<NDW, STORE, COMPACT>(ring[u % RING], A, HR[u & 1], HR[(u & 1) ^ 1], tt >= 4 && tt < T, active,
+                                        first_lane, last_lane, lh,
+                                        reinterpret_cast<uint32_t *>(dbase + (ptrdiff_t)y * W), cp,
+                                        (uint32_t)(y * W + xoff));
         }
     }
 
