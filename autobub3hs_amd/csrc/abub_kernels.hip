@@ -340,22 +340,36 @@ __device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, K2Ro
     }
 
     // ---- vertical 1-4-6-4-1, (S+128)>>8, absdiff (AnalyzerUnit.cpp:370) -----------------------
-    uint32_t Dp[NP];
-    uint32_t any = 0;
+    uint32_t Vp[NP], Vn[NP];
+    uint32_t big = 0; // OR of all sums: if no u16 lane reaches 256 every rounded value, hence D, is 0
 #pragma unroll
     for (int j = 0; j < NP; j++) {
-        uint32_t vp = A.pa0[j] + Hp[j];
-        uint32_t vn = A.na0[j] + Hn[j];
+        Vp[j] = A.pa0[j] + Hp[j];
+        Vn[j] = A.na0[j] + Hn[j];
         A.pa0[j] = lshl2_add(Hp[j], A.pa1[j]);
         A.na0[j] = lshl2_add(Hn[j], A.na1[j]);
         A.pa1[j] = pk_madk<6>(Hp[j], A.pa2[j]);
         A.na1[j] = pk_madk<6>(Hn[j], A.na2[j]);
         A.pa2[j] = lshl2_add(Hp[j], Hprev.hp[j]);
         A.na2[j] = lshl2_add(Hn[j], Hprev.hn[j]);
-        uint32_t rp = __builtin_amdgcn_perm(0u, vp, 0x0c030c01u); // byte1, byte3 of the u16 lanes
-        uint32_t rn = __builtin_amdgcn_perm(0u, vn, 0x0c030c01u);
-        Dp[j] = pk_absdiff(rp, rn);
-        any |= Dp[j];
+        big |= Vp[j] | Vn[j];
+    }
+    uint32_t Dp[NP];
+    uint32_t any = 0;
+    // wave-uniform shortcut: for almost every row of almost every frame all sums stay below 256
+    const bool quiet = __builtin_amdgcn_ballot_w64((big & 0xff00ff00u) != 0) == 0;
+    if (quiet) {
+#pragma unroll
+        for (int j = 0; j < NP; j++)
+            Dp[j] = 0;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            uint32_t rp = __builtin_amdgcn_perm(0u, Vp[j], 0x0c030c01u); // byte1, byte3 of the u16 lanes
+            uint32_t rn = __builtin_amdgcn_perm(0u, Vn[j], 0x0c030c01u);
+            Dp[j] = pk_absdiff(rp, rn);
+            any |= Dp[j];
+        }
     }
 
     if (emit) {
@@ -610,7 +624,15 @@ static void launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const a
 {
     // prefetch depth 1 won on MI355X: depth 2/3 rings cost a wave of occupancy and ran 10-17 % slower
     // (measured in round 1, see DESIGN.md "Tuning log")
-    launch_k2_rows_pf<NDW, 1>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st);
+    static int pf = -1;
+    if (pf < 0) {
+        const char *e = getenv("ABUB_K2_PF"); // tuning knob: software-prefetch depth in rows (1 or 2)
+        pf = e ? atoi(e) : 1;
+    }
+    if (pf == 2)
+        launch_k2_rows_pf<NDW, 2>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st);
+    else
+        launch_k2_rows_pf<NDW, 1>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st);
 }
 
 static int diff_hist_impl(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs, int njobs,
