@@ -13,6 +13,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <memory>
@@ -146,38 +147,64 @@ double nowMs()
 
 } // namespace
 
+// One slice of the run with its own stream and scratch: groups run concurrently on host threads, so the
+// GPU work of one group overlaps the host state machines of another (no group waits on another).
+struct Group {
+    int s0 = 0, s1 = 0; // stacks [s0, s1)
+    hipStream_t stream = nullptr;
+    hipEvent_t stage1Done = nullptr;
+    abub_job *d_jobs1 = nullptr;
+    uint32_t *d_hist1 = nullptr;
+    abub_job *d_jobs3 = nullptr;
+    uint32_t *d_hist3 = nullptr;
+    uint8_t *d_img = nullptr;
+    int32_t *d_thr = nullptr;
+    uint32_t *d_pairs = nullptr, *d_count = nullptr, *d_gscratch = nullptr, *d_goff = nullptr, *d_gidx = nullptr;
+    uint8_t *d_gval = nullptr;
+    uint32_t *h_hist1 = nullptr, *h_hist3 = nullptr, *h_count = nullptr, *h_goff = nullptr, *h_gidx = nullptr;
+    uint8_t *h_gval = nullptr;
+    abub_job *h_jobs3 = nullptr;
+    int32_t *h_thr = nullptr;
+    uint32_t pairCap = 0;
+    int nthreads = 1;
+    double tms[8] = {0};
+    int rounds = 0;
+    uint32_t lastPairs = 0;
+    std::string error;
+};
+
 class RunPipeline {
 public:
-    int device, W, H, F, E, C, S, nthreads;
+    int device, W, H, F, E, C, S, nthreads, ngroups;
     size_t P;
     std::vector<int> tss;
     std::string maskDir;
-    // device scratch
-    abub_job *d_jobs1 = nullptr;   // stage-1 job list [S*(F-1)]
-    uint32_t *d_hist1 = nullptr;   // [S*(F-1)][256]
-    abub_job *d_jobs3 = nullptr;   // per-round jobs [S*11]
-    uint32_t *d_hist3 = nullptr;   // [S*11][256]
-    uint8_t *d_img = nullptr;      // [S*11][H][W]
-    int32_t *d_thr = nullptr;      // [S*11]
-    uint32_t *d_pairs = nullptr;   // [cap][2]
-    uint32_t *d_count = nullptr;
-    uint32_t *d_gscratch = nullptr, *d_goff = nullptr, *d_gidx = nullptr; // grouped list
-    uint8_t *d_gval = nullptr;
-    uint32_t *h_goff = nullptr, *h_gidx = nullptr;
-    uint8_t *h_gval = nullptr;
-    uint32_t pairCap = 0;
-    // pinned host
-    uint32_t *h_hist1 = nullptr, *h_hist3 = nullptr, *h_pairs = nullptr, *h_count = nullptr;
-    abub_job *h_jobs3 = nullptr;
-    int32_t *h_thr = nullptr;
-    hipStream_t stream = nullptr;
-    bool ownStream = false;
+    std::vector<Group> groups;
+    hipStream_t stage1Stream = nullptr; // all trigger-search launches, in group order (see run())
+    std::vector<void *> devAllocs, hostAllocs;
     std::vector<StackState> stacks;
     std::vector<Trainer *> trainers;
     MemParser parser;
     double tms[8] = {0};
     int rounds = 0;
     uint32_t lastPairs = 0;
+
+    template <typename T>
+    T *dalloc(size_t n)
+    {
+        void *p = nullptr;
+        HIPOK(hipMalloc(&p, n * sizeof(T) + 256));
+        devAllocs.push_back(p);
+        return (T *)p;
+    }
+    template <typename T>
+    T *halloc(size_t n)
+    {
+        void *p = nullptr;
+        HIPOK(hipHostMalloc(&p, n * sizeof(T) + 256, hipHostMallocDefault));
+        hostAllocs.push_back(p);
+        return (T *)p;
+    }
 
     RunPipeline(int device_, int W_, int H_, int F_, int E_, int C_, const int *tss_, int nthreads_, const char *maskdir)
         : device(device_), W(W_), H(H_), F(F_), E(E_), C(C_), S(E_ * C_), nthreads(nthreads_), P((size_t)W_ * H_),
@@ -186,44 +213,64 @@ public:
         if (W <= 0 || H <= 0 || F <= 0 || E <= 0 || C <= 0)
             throw std::runtime_error("RunPipeline: bad geometry");
         HIPOK(hipSetDevice(device));
-        const size_t n1 = (size_t)S * std::max(F - 1, 1), n3 = (size_t)S * (NumFramesBubbleTrack + 1);
-        pairCap = 8u << 20;
-        HIPOK(hipMalloc((void **)&d_jobs1, n1 * sizeof(abub_job)));
-        HIPOK(hipMalloc((void **)&d_hist1, n1 * 1024));
-        HIPOK(hipMalloc((void **)&d_jobs3, n3 * sizeof(abub_job)));
-        HIPOK(hipMalloc((void **)&d_hist3, n3 * 1024));
-        HIPOK(hipMalloc((void **)&d_img, n3 * P));
-        HIPOK(hipMalloc((void **)&d_thr, n3 * sizeof(int32_t)));
-        HIPOK(hipMalloc((void **)&d_pairs, (size_t)pairCap * 8));
-        HIPOK(hipMalloc((void **)&d_count, sizeof(uint32_t)));
-        HIPOK(hipMalloc((void **)&d_gscratch, 2 * n3 * sizeof(uint32_t)));
-        HIPOK(hipMalloc((void **)&d_goff, (n3 + 1) * sizeof(uint32_t)));
-        HIPOK(hipMalloc((void **)&d_gidx, (size_t)pairCap * 4));
-        HIPOK(hipMalloc((void **)&d_gval, (size_t)pairCap));
-        HIPOK(hipHostMalloc((void **)&h_goff, (n3 + 1) * sizeof(uint32_t), hipHostMallocDefault));
-        HIPOK(hipHostMalloc((void **)&h_gidx, (size_t)pairCap * 4, hipHostMallocDefault));
-        HIPOK(hipHostMalloc((void **)&h_gval, (size_t)pairCap, hipHostMallocDefault));
-        HIPOK(hipHostMalloc((void **)&h_hist1, n1 * 1024, hipHostMallocDefault));
-        HIPOK(hipHostMalloc((void **)&h_hist3, n3 * 1024, hipHostMallocDefault));
-        HIPOK(hipHostMalloc((void **)&h_pairs, (size_t)pairCap * 8, hipHostMallocDefault));
-        HIPOK(hipHostMalloc((void **)&h_count, sizeof(uint32_t), hipHostMallocDefault));
-        HIPOK(hipHostMalloc((void **)&h_jobs3, n3 * sizeof(abub_job), hipHostMallocDefault));
-        HIPOK(hipHostMalloc((void **)&h_thr, n3 * sizeof(int32_t), hipHostMallocDefault));
+        const char *eg = getenv("ABUB_PIPE_GROUPS");
+        ngroups = eg ? atoi(eg) : 2;
+        int prLow = 0, prHigh = 0; // (numerically lower = higher priority)
+        HIPOK(hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
+        HIPOK(hipStreamCreateWithPriority(&stage1Stream, hipStreamNonBlocking, prLow));
+        if (ngroups < 1)
+            ngroups = 1;
+        if (ngroups > S)
+            ngroups = S;
+        const int K = NumFramesBubbleTrack + 1;
+        groups.resize(ngroups);
         // stage-1 jobs: FindTriggerFrame's pairing, ref = max(i - off, 0) with off = 1 when the model was
-        // trained on fewer than 6 frames (AnalyzerUnit.cpp:185-188)
-        std::vector<abub_job> j1(n1);
-        for (int s = 0; s < S; ++s) {
-            const int c = s % C, off = tss[c] < 6 ? 1 : 2;
-            for (int i = 1; i < F; ++i) {
-                abub_job &j = j1[(size_t)s * (F - 1) + (i - 1)];
-                j.cur = (uint32_t)(s * F + i);
-                j.ref = (uint32_t)(s * F + std::max(i - off, 0));
-                j.model = (uint32_t)c;
-                j.out = (uint32_t)((size_t)s * (F - 1) + (i - 1));
+        // trained on fewer than 6 frames (AnalyzerUnit.cpp:185-188); `out` is relative to the group's slab
+        for (int g = 0; g < ngroups; ++g) {
+            Group &G = groups[g];
+            G.s0 = (int)((long long)S * g / ngroups);
+            G.s1 = (int)((long long)S * (g + 1) / ngroups);
+            const size_t ns = (size_t)(G.s1 - G.s0), n1 = ns * std::max(F - 1, 1), n3 = ns * K;
+            G.nthreads = std::max(1, nthreads / ngroups);
+            G.pairCap = (8u << 20) / ngroups;
+            // the short localisation launches of a finished group must not queue behind the next group's
+            // chip-filling trigger search
+            HIPOK(hipStreamCreateWithPriority(&G.stream, hipStreamNonBlocking, prHigh));
+            HIPOK(hipEventCreateWithFlags(&G.stage1Done, hipEventDisableTiming));
+            G.d_jobs1 = dalloc<abub_job>(n1);
+            G.d_hist1 = dalloc<uint32_t>(n1 * 256);
+            G.d_jobs3 = dalloc<abub_job>(n3);
+            G.d_hist3 = dalloc<uint32_t>(n3 * 256);
+            G.d_img = dalloc<uint8_t>(abub_fast_path(W) ? 256 : n3 * P); // only the unfused fallback stores images
+            G.d_thr = dalloc<int32_t>(n3);
+            G.d_pairs = dalloc<uint32_t>((size_t)G.pairCap * 2);
+            G.d_count = dalloc<uint32_t>(1);
+            G.d_gscratch = dalloc<uint32_t>(2 * n3);
+            G.d_goff = dalloc<uint32_t>(n3 + 1);
+            G.d_gidx = dalloc<uint32_t>(G.pairCap);
+            G.d_gval = dalloc<uint8_t>(G.pairCap);
+            G.h_hist1 = halloc<uint32_t>(n1 * 256);
+            G.h_hist3 = halloc<uint32_t>(n3 * 256);
+            G.h_count = halloc<uint32_t>(1);
+            G.h_goff = halloc<uint32_t>(n3 + 1);
+            G.h_gidx = halloc<uint32_t>(G.pairCap);
+            G.h_gval = halloc<uint8_t>(G.pairCap);
+            G.h_jobs3 = halloc<abub_job>(n3);
+            G.h_thr = halloc<int32_t>(n3);
+            std::vector<abub_job> j1(n1);
+            for (int s = G.s0; s < G.s1; ++s) {
+                const int c = s % C, off = tss[c] < 6 ? 1 : 2;
+                for (int i = 1; i < F; ++i) {
+                    abub_job &j = j1[(size_t)(s - G.s0) * (F - 1) + (i - 1)];
+                    j.cur = (uint32_t)(s * F + i);
+                    j.ref = (uint32_t)(s * F + std::max(i - off, 0));
+                    j.model = (uint32_t)c;
+                    j.out = (uint32_t)((size_t)(s - G.s0) * (F - 1) + (i - 1));
+                }
             }
+            if (F > 1)
+                HIPOK(hipMemcpy(G.d_jobs1, j1.data(), n1 * sizeof(abub_job), hipMemcpyHostToDevice));
         }
-        if (F > 1)
-            HIPOK(hipMemcpy(d_jobs1, j1.data(), n1 * sizeof(abub_job), hipMemcpyHostToDevice));
         // frame names only: the images live in HBM
         for (int c = 0; c < C; ++c) {
             Trainer *t = new Trainer(c, {}, "", "cam%d_image%u.png", "", parser.clone(), false);
@@ -240,49 +287,85 @@ public:
     ~RunPipeline()
     {
         (void)hipSetDevice(device);
-        (void)hipFree(d_jobs1);
-        (void)hipFree(d_hist1);
-        (void)hipFree(d_jobs3);
-        (void)hipFree(d_hist3);
-        (void)hipFree(d_img);
-        (void)hipFree(d_thr);
-        (void)hipFree(d_pairs);
-        (void)hipFree(d_count);
-        (void)hipFree(d_gscratch);
-        (void)hipFree(d_goff);
-        (void)hipFree(d_gidx);
-        (void)hipFree(d_gval);
-        (void)hipHostFree(h_goff);
-        (void)hipHostFree(h_gidx);
-        (void)hipHostFree(h_gval);
-        (void)hipHostFree(h_hist1);
-        (void)hipHostFree(h_hist3);
-        (void)hipHostFree(h_pairs);
-        (void)hipHostFree(h_count);
-        (void)hipHostFree(h_jobs3);
-        (void)hipHostFree(h_thr);
+        for (Group &G : groups) {
+            if (G.stream)
+                (void)hipStreamDestroy(G.stream);
+            if (G.stage1Done)
+                (void)hipEventDestroy(G.stage1Done);
+        }
+        if (stage1Stream)
+            (void)hipStreamDestroy(stage1Stream);
+        for (void *p : devAllocs)
+            (void)hipFree(p);
+        for (void *p : hostAllocs)
+            (void)hipHostFree(p);
         for (Trainer *t : trainers)
             delete t;
     }
 
-    void run(const uint8_t *d_frames, const uint8_t *d_mu, const uint8_t *d_sigma6, hipStream_t st)
+    // `callerStream`: work already queued there (e.g. the upload of the frames) is waited for first
+    void run(const uint8_t *d_frames, const uint8_t *d_mu, const uint8_t *d_sigma6, hipStream_t callerStream)
     {
         HIPOK(hipSetDevice(device));
+        HIPOK(hipStreamSynchronize(callerStream));
         g_quietAnalyzers = true;
-        stream = st;
-        std::fill(tms, tms + 8, 0.0);
-        rounds = 0;
         double t0 = nowMs();
-        // ---- stage 1 -------------------------------------------------------------------------
-        const int n1 = S * (F - 1);
-        if (n1 > 0) {
-            check(abub_diff_hist_dev(d_frames, d_sigma6, d_jobs1, n1, W, H, d_hist1, nullptr, 0, stream), "stage1 K2");
-            HIPOK(hipMemcpyAsync(h_hist1, d_hist1, (size_t)n1 * 1024, hipMemcpyDeviceToHost, stream));
-        }
-        // analyzers are (re)built while the GPU works
         stacks.clear();
         stacks.resize(S);
-        parallelFor(S, nthreads, [&](int s) {
+        // Stage 1 of every group goes to ONE stream in group order: the trigger search of group g+1 runs
+        // on the GPU while the host threads of group g are in their state machines (two kernels launched on
+        // different streams would simply share the chip and finish together, leaving nothing to overlap).
+        for (Group &G : groups) {
+            const int n1 = (G.s1 - G.s0) * (F - 1);
+            if (n1 > 0) {
+                check(abub_diff_hist_dev(d_frames, d_sigma6, G.d_jobs1, n1, W, H, G.d_hist1, nullptr, 0, stage1Stream),
+                      "stage1 K2");
+                HIPOK(hipMemcpyAsync(G.h_hist1, G.d_hist1, (size_t)n1 * 1024, hipMemcpyDeviceToHost, stage1Stream));
+            }
+            HIPOK(hipEventRecord(G.stage1Done, stage1Stream));
+        }
+        std::vector<std::thread> th;
+        for (int g = 1; g < ngroups; ++g)
+            th.emplace_back([&, g]() { runGroupNoThrow(groups[g], d_frames, d_mu, d_sigma6); });
+        runGroupNoThrow(groups[0], d_frames, d_mu, d_sigma6);
+        for (auto &t : th)
+            t.join();
+        std::fill(tms, tms + 8, 0.0);
+        rounds = 0;
+        lastPairs = 0;
+        for (Group &G : groups) {
+            if (!G.error.empty())
+                throw std::runtime_error(G.error);
+            for (int k = 0; k < 8; ++k)
+                tms[k] = std::max(tms[k], G.tms[k]);
+            rounds = std::max(rounds, G.rounds);
+            lastPairs += G.lastPairs;
+        }
+        tms[4] = nowMs() - t0;
+    }
+
+private:
+    void runGroupNoThrow(Group &G, const uint8_t *d_frames, const uint8_t *d_mu, const uint8_t *d_sigma6)
+    {
+        G.error.clear();
+        try {
+            (void)hipSetDevice(device);
+            runGroup(G, d_frames, d_mu, d_sigma6);
+        } catch (std::exception &e) {
+            G.error = e.what();
+        }
+    }
+
+    void runGroup(Group &G, const uint8_t *d_frames, const uint8_t *d_mu, const uint8_t *d_sigma6)
+    {
+        std::fill(G.tms, G.tms + 8, 0.0);
+        G.rounds = 0;
+        const int ns = G.s1 - G.s0;
+        double t0 = nowMs();
+        // ---- stage 1 (already queued by run()) -----------------------------------------------------
+        // analyzers are (re)built while the GPU works
+        parallelFor(ns, G.nthreads, [&](int k) {
+            const int s = G.s0 + k;
             StackState &st_ = stacks[s];
             const int e = s / C, c = s % C;
             Trainer *t = trainers[c];
@@ -291,21 +374,21 @@ public:
             st_.data.W = W;
             st_.data.H = H;
             st_.data.refOffset = tss[c] < 6 ? 1 : 2;
-            st_.data.hists = h_hist1 + (size_t)s * (F - 1) * 256;
+            st_.data.hists = G.h_hist1 + (size_t)k * (F - 1) * 256;
             st_.analyzer->AttachEventData(&st_.data);
         });
-        HIPOK(hipStreamSynchronize(stream));
-        tms[0] = nowMs() - t0;
+        HIPOK(hipEventSynchronize(G.stage1Done));
+        G.tms[0] = nowMs() - t0;
 
-        std::vector<int> pending(S);
-        for (int s = 0; s < S; ++s)
-            pending[s] = s;
+        std::vector<int> pending(ns);
+        for (int k = 0; k < ns; ++k)
+            pending[k] = G.s0 + k;
         while (!pending.empty()) {
-            ++rounds;
+            ++G.rounds;
             // ---- stage 2: trigger search + plan ------------------------------------------------
             double t2 = nowMs();
-            parallelFor((int)pending.size(), nthreads, [&](int k) { triggerAndPlan(stacks[pending[k]]); });
-            tms[1] += nowMs() - t2;
+            parallelFor((int)pending.size(), G.nthreads, [&](int k) { triggerAndPlan(stacks[pending[k]]); });
+            G.tms[1] += nowMs() - t2;
             // ---- stage 3: batched images, thresholds, foreground ---------------------------------
             double t3 = nowMs();
             std::vector<int> loc;
@@ -313,12 +396,12 @@ public:
                 if (stacks[s].localize)
                     loc.push_back(s);
             if (!loc.empty())
-                batchImages(loc, d_frames, d_mu, d_sigma6);
-            tms[2] += nowMs() - t3;
+                batchImages(G, loc, d_frames, d_mu, d_sigma6);
+            G.tms[2] += nowMs() - t3;
             // ---- stage 4: localize + track -------------------------------------------------------
             double t4 = nowMs();
-            parallelFor((int)loc.size(), nthreads, [&](int k) { localize(stacks[loc[k]]); });
-            tms[3] += nowMs() - t4;
+            parallelFor((int)loc.size(), G.nthreads, [&](int k) { localize(stacks[loc[k]]); });
+            G.tms[3] += nowMs() - t4;
             std::vector<int> next;
             for (int s : pending)
                 if (!stacks[s].done)
@@ -326,8 +409,8 @@ public:
             pending.swap(next);
         }
         // results out, analyzers released
-        parallelFor(S, nthreads, [&](int s) {
-            StackState &st_ = stacks[s];
+        parallelFor(ns, G.nthreads, [&](int k) {
+            StackState &st_ = stacks[G.s0 + k];
             AnalyzerUnit *A = st_.analyzer.get();
             st_.trig = A->MatTrigFrame;
             st_.status = A->TriggerFrameIdentificationStatus;
@@ -343,10 +426,8 @@ public:
             }
             st_.analyzer.reset();
         });
-        tms[4] = nowMs() - t0;
     }
 
-private:
     // AnyCamAnalysis body up to LocalizeOMatic (AutoBubStart3.cpp:87-107)
     void triggerAndPlan(StackState &st_)
     {
@@ -398,9 +479,11 @@ private:
         }
     }
 
-    void batchImages(const std::vector<int> &loc, const uint8_t *d_frames, const uint8_t *d_mu, const uint8_t *d_sigma6)
+    void batchImages(Group &G, const std::vector<int> &loc, const uint8_t *d_frames, const uint8_t *d_mu,
+                     const uint8_t *d_sigma6)
     {
-        // slots: all genesis images first (K2 store), then all post-trigger images (K3)
+        hipStream_t stream = G.stream;
+        // slots: all genesis images first (K2), then all post-trigger images (K3)
         int nd = 0, np = 0;
         for (int s : loc)
             for (PlannedImage &p : stacks[s].data.planned)
@@ -410,7 +493,7 @@ private:
             const int c = s % C;
             for (PlannedImage &p : stacks[s].data.planned) {
                 p.slot = p.kind == 0 ? di++ : pi++;
-                abub_job &j = h_jobs3[p.slot];
+                abub_job &j = G.h_jobs3[p.slot];
                 j.cur = (uint32_t)(s * F + p.i);
                 j.ref = (uint32_t)(s * F + p.ref);
                 j.model = (uint32_t)c;
@@ -421,61 +504,64 @@ private:
         double ta = nowMs();
         std::vector<PlannedImage *> bySlot((size_t)nimg);
         for (int s : loc) {
-            stacks[s].data.roundHists = h_hist3;
+            stacks[s].data.roundHists = G.h_hist3;
             for (PlannedImage &p : stacks[s].data.planned) {
                 bySlot[p.slot] = &p;
-                h_thr[p.slot] = p.tozero; // candidate cut = TOZERO threshold, known before the launch
+                G.h_thr[p.slot] = p.tozero; // candidate cut = TOZERO threshold, known before the launch
             }
         }
-        HIPOK(hipMemcpyAsync(d_jobs3, h_jobs3, (size_t)nimg * sizeof(abub_job), hipMemcpyHostToDevice, stream));
-        HIPOK(hipMemcpyAsync(d_thr, h_thr, (size_t)nimg * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-        HIPOK(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
+        HIPOK(hipMemcpyAsync(G.d_jobs3, G.h_jobs3, (size_t)nimg * sizeof(abub_job), hipMemcpyHostToDevice, stream));
+        HIPOK(hipMemcpyAsync(G.d_thr, G.h_thr, (size_t)nimg * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        HIPOK(hipMemsetAsync(G.d_count, 0, sizeof(uint32_t), stream));
         const bool fused = abub_fast_path(W) != 0;
         if (fused) {
             // images are never materialised: histogram + candidate list come out of the same pass
-            check(abub_diff_hist_compact_dev(d_frames, d_sigma6, d_jobs3, nd, W, H, d_hist3, nullptr, d_thr, d_pairs,
-                                             pairCap, d_count, 0, stream),
+            check(abub_diff_hist_compact_dev(d_frames, d_sigma6, G.d_jobs3, nd, W, H, G.d_hist3, nullptr, G.d_thr,
+                                             G.d_pairs, G.pairCap, G.d_count, 0, stream),
                   "stage3 K2 compact");
             if (np > 0)
-                check(abub_posttrig_compact_dev(d_frames, d_mu, d_sigma6, d_jobs3 + nd, np, W, H,
-                                                d_hist3 + (size_t)nd * 256, nullptr, d_thr + nd, d_pairs, pairCap,
-                                                d_count, (uint32_t)nd, stream),
+                check(abub_posttrig_compact_dev(d_frames, d_mu, d_sigma6, G.d_jobs3 + nd, np, W, H,
+                                                G.d_hist3 + (size_t)nd * 256, nullptr, G.d_thr + nd, G.d_pairs,
+                                                G.pairCap, G.d_count, (uint32_t)nd, stream),
                       "stage3 K3 compact");
         } else {
-            check(abub_diff_hist_dev(d_frames, d_sigma6, d_jobs3, nd, W, H, d_hist3, d_img, 0, stream), "stage3 K2 store");
+            check(abub_diff_hist_dev(d_frames, d_sigma6, G.d_jobs3, nd, W, H, G.d_hist3, G.d_img, 0, stream),
+                  "stage3 K2 store");
             if (np > 0)
-                check(abub_posttrig_dev(d_frames, d_mu, d_sigma6, d_jobs3 + nd, np, W, H, d_hist3 + (size_t)nd * 256,
-                                        d_img + (size_t)nd * P, stream),
+                check(abub_posttrig_dev(d_frames, d_mu, d_sigma6, G.d_jobs3 + nd, np, W, H, G.d_hist3 + (size_t)nd * 256,
+                                        G.d_img + (size_t)nd * P, stream),
                       "stage3 K3");
-            check(abub_fg_compact_pairs_dev(d_img, nimg, W, H, d_thr, d_pairs, pairCap, d_count, stream), "stage3 K4");
+            check(abub_fg_compact_pairs_dev(G.d_img, nimg, W, H, G.d_thr, G.d_pairs, G.pairCap, G.d_count, stream),
+                  "stage3 K4");
         }
         // group the list by image on the device; the host gets contiguous runs and never re-buckets
-        check(abub_pairs_group_dev(d_pairs, d_count, pairCap, nimg, d_gscratch, d_goff, d_gidx, d_gval, stream),
+        check(abub_pairs_group_dev(G.d_pairs, G.d_count, G.pairCap, nimg, G.d_gscratch, G.d_goff, G.d_gidx, G.d_gval,
+                                   stream),
               "stage3 group");
-        HIPOK(hipMemcpyAsync(h_hist3, d_hist3, (size_t)nimg * 1024, hipMemcpyDeviceToHost, stream));
-        HIPOK(hipMemcpyAsync(h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        HIPOK(hipMemcpyAsync(h_goff, d_goff, (size_t)(nimg + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIPOK(hipMemcpyAsync(G.h_hist3, G.d_hist3, (size_t)nimg * 1024, hipMemcpyDeviceToHost, stream));
+        HIPOK(hipMemcpyAsync(G.h_count, G.d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIPOK(hipMemcpyAsync(G.h_goff, G.d_goff, (size_t)(nimg + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIPOK(hipStreamSynchronize(stream));
-        tms[5] += nowMs() - ta; // launches + kernels + hist/count D2H
+        G.tms[5] += nowMs() - ta; // launches + kernels + hist/count D2H
         ta = nowMs();
-        const uint32_t cnt = *h_count;
-        lastPairs = cnt;
-        if (cnt > pairCap)
+        const uint32_t cnt = *G.h_count;
+        G.lastPairs = cnt;
+        if (cnt > G.pairCap)
             throw std::runtime_error("RunPipeline: foreground list overflow (dense foreground in too many images)");
         if (cnt) {
-            HIPOK(hipMemcpyAsync(h_gidx, d_gidx, (size_t)cnt * 4, hipMemcpyDeviceToHost, stream));
-            HIPOK(hipMemcpyAsync(h_gval, d_gval, (size_t)cnt, hipMemcpyDeviceToHost, stream));
+            HIPOK(hipMemcpyAsync(G.h_gidx, G.d_gidx, (size_t)cnt * 4, hipMemcpyDeviceToHost, stream));
+            HIPOK(hipMemcpyAsync(G.h_gval, G.d_gval, (size_t)cnt, hipMemcpyDeviceToHost, stream));
         }
         // thresholds (TOZERO + Otsu) on the host from the histograms, while the list travels
-        parallelFor(nimg, nthreads, [&](int k) {
+        parallelFor(nimg, G.nthreads, [&](int k) {
             PlannedImage *p = bySlot[k];
-            p->thr = binarizeThresholdFromHist(h_hist3 + (size_t)k * 256, P, p->tozero);
-            p->fg = h_gidx + h_goff[k];
-            p->fgv = h_gval + h_goff[k];
-            p->nfg = h_goff[k + 1] - h_goff[k];
+            p->thr = binarizeThresholdFromHist(G.h_hist3 + (size_t)k * 256, P, p->tozero);
+            p->fg = G.h_gidx + G.h_goff[k];
+            p->fgv = G.h_gval + G.h_goff[k];
+            p->nfg = G.h_goff[k + 1] - G.h_goff[k];
         });
         HIPOK(hipStreamSynchronize(stream));
-        tms[6] += nowMs() - ta; // list D2H (+ thresholds)
+        G.tms[6] += nowMs() - ta; // list D2H (+ thresholds)
     }
 
     // AnyCamAnalysis body from LocalizeOMatic on (AutoBubStart3.cpp:94-110)
