@@ -50,6 +50,8 @@ def lib():
         L.abh_last_dzdt.restype = C.c_float
         L.abh_last_drdt.argtypes = [C.c_void_p, C.c_int]
         L.abh_last_drdt.restype = C.c_float
+        L.abh_write_header.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+        L.abh_event_to_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         L.abh_contours.argtypes = [_u32p, C.c_int, C.c_int, C.c_int, _ip, _ip, C.c_int, C.c_int]
         L.abh_binarize_threshold.argtypes = [_u32p, C.c_int, C.c_int]
         L.abh_entropy.argtypes = [_u32p, C.c_int, C.c_int]
@@ -67,10 +69,39 @@ DESC_KEYS = ("x", "y", "w", "h", "area", "radius", "m00", "m10", "m01", "cx", "c
 
 
 class Run:
-    """An in-memory run: events added per camera, trained, then analysed per (event, camera)."""
+    """A run: in memory (events added per camera), a directory tree (kind="raw") or a zip archive (kind="zip");
+    trained per camera, then analysed per (event, camera)."""
 
-    def __init__(self):
-        self._h = lib().abh_run_new()
+    def __init__(self, kind=None, run_folder="", image_folder="Images", image_format="cam%d_image%u.png"):
+        L = lib()
+        L.abh_run_open.restype = C.c_void_p
+        L.abh_run_open.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
+        L.abh_run_events.restype = C.c_char_p
+        L.abh_run_events.argtypes = [C.c_void_p]
+        L.abh_run_frames.restype = C.c_char_p
+        L.abh_run_frames.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.abh_run_image.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, _u8p, C.c_int, _ip, _ip]
+        if kind is None:
+            self._h = L.abh_run_new()
+        else:
+            self._h = L.abh_run_open(0 if kind == "raw" else 1, run_folder.encode(), image_folder.encode(),
+                                     image_format.encode())
+            if not self._h:
+                raise RuntimeError(f"cannot open run source {run_folder!r} (status -10 upstream)")
+
+    def events(self):
+        return [e for e in lib().abh_run_events(self._h).decode().split("\n") if e]
+
+    def frames(self, event, cam):
+        return [f for f in lib().abh_run_frames(self._h, str(event).encode(), cam).decode().split("\n") if f]
+
+    def image(self, event, frame, cap=1 << 22):
+        buf = np.empty(cap, np.uint8)
+        w, h = C.c_int(), C.c_int()
+        rc = lib().abh_run_image(self._h, str(event).encode(), frame.encode(), buf.ctypes.data_as(_u8p), cap,
+                                 C.byref(w), C.byref(h))
+        img = buf[: w.value * h.value].reshape(h.value, w.value).copy() if w.value * h.value else None
+        return rc, img
 
     def close(self):
         if self._h:
@@ -93,8 +124,8 @@ class Run:
         lib().abh_run_add_event(self._h, str(event).encode(), cam, frames.ctypes.data_as(_u8p), F, W, H, okp)
         self._shape = (H, W)
 
-    def train(self, cam):
-        H, W = self._shape
+    def train(self, cam, shape=None):
+        H, W = shape if shape is not None else self._shape
         mu = np.zeros((H, W), np.uint8)
         sg = np.zeros((H, W), np.uint8)
         st, tss = C.c_int(), C.c_int()
@@ -130,6 +161,46 @@ class Run:
             bubbles.append({"desc": descs, "dz": dz, "dzdt": L.abh_last_dzdt(self._h, b),
                             "drdt": L.abh_last_drdt(self._h, b)})
         return staged, state, bubbles, L.abh_last_error(self._h).decode()
+
+
+def imdecode(data, cap=1 << 22):
+    L = lib()
+    L.abh_imdecode.argtypes = [_u8p, C.c_int, _u8p, C.c_int, _ip, _ip]
+    src = np.frombuffer(data, np.uint8)
+    out = np.empty(cap, np.uint8)
+    w, h = C.c_int(), C.c_int()
+    rc = L.abh_imdecode(src.ctypes.data_as(_u8p), len(src), out.ctypes.data_as(_u8p), cap, C.byref(w), C.byref(h))
+    if rc != 0:
+        return None
+    return out[: w.value * h.value].reshape(h.value, w.value).copy()
+
+
+def write_header(outdir, run_number, frame_offset, ncams):
+    """OutputWriter::writeHeader -> <outdir>abub3hs_<run>.txt (outdir is used as a prefix, like upstream)."""
+    lib().abh_write_header(outdir.encode(), run_number.encode(), frame_offset, ncams)
+
+
+def event_to_file(run, event, actual_event_number, ncams, outdir, run_number, frame_offset, maskdir=""):
+    """One iteration of the reference's event loop: analyse every camera, append the block to the file."""
+    rc = lib().abh_event_to_file(run._h, str(event).encode(), int(actual_event_number), ncams, maskdir.encode(),
+                                 outdir.encode(), run_number.encode(), frame_offset)
+    if rc != 0:
+        raise RuntimeError("abh_event_to_file failed")
+
+
+def writer_probe(outdir, run_number, frame_offset, event, cams):
+    """cams: list of (status, frame0, bubbles) with bubbles = list of descriptor-row lists (11 numbers each)."""
+    L = lib()
+    L.abh_writer_probe.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip, _dp]
+    n = len(cams)
+    status = (C.c_int * n)(*[c[0] for c in cams])
+    frame0 = (C.c_int * n)(*[c[1] for c in cams])
+    nbub = (C.c_int * n)(*[len(c[2]) for c in cams])
+    nd = [len(b) for c in cams for b in c[2]]
+    ndesc = (C.c_int * max(1, len(nd)))(*nd)
+    rows = [float(v) for c in cams for b in c[2] for d in b for v in d]
+    desc = (C.c_double * max(1, len(rows)))(*rows)
+    L.abh_writer_probe(outdir.encode(), run_number.encode(), frame_offset, n, event, status, frame0, nbub, ndesc, desc)
 
 
 # ---- host-logic probes (CPU only) ---------------------------------------------------------------

@@ -6,9 +6,15 @@
 
 Parser::~Parser() {}
 
-// reference ParseFolder/Parser.cpp: cross-checks the event list against GetRunFileInfo; nothing in
-// the hot path depends on it.  Kept as a no-op consistency hook.
-void Parser::VerifyEventList(std::vector<std::string> &) {}
+// keep only the events the run file knows about (reference ParseFolder/Parser.cpp:14-26)
+void Parser::VerifyEventList(std::vector<std::string> &EventList)
+{
+    std::vector<std::string> known;
+    GetRunFileInfo(known);
+    EventList.erase(std::remove_if(EventList.begin(), EventList.end(),
+                                   [&](const std::string &e) { return std::find(known.begin(), known.end(), e) == known.end(); }),
+                    EventList.end());
+}
 
 void MemParser::AddFrames(const std::string &EventID, int camera, const std::vector<cv::Mat> &frames, int firstIndex)
 {

@@ -13,7 +13,10 @@
 #include "AlgorithmTraining/Trainer.hpp"
 #include "AnalyzerUnit.hpp"
 #include "BubbleLocalizer/L3Localizer.hpp"
+#include "PICOFormatWriter/PICOFormatWriterV4.hpp"
 #include "ParseFolder/Parser.hpp"
+#include "ParseFolder/RawParser.hpp"
+#include "ParseFolder/ZipParser.hpp"
 #include "devctx.hpp"
 #include "hostlogic.hpp"
 
@@ -26,7 +29,9 @@ struct BubbleOut {
 };
 
 struct Run {
-    MemParser parser;
+    Parser *parser = nullptr; // MemParser (tests / synthetic), RawParser or ZipParser
+    MemParser *mem = nullptr;
+    std::string frames_of_last_query;
     std::map<int, Trainer *> trainers;
     // last analysis
     int staged = 0, trig = 0, status = 0, loc_thres = 0, ok = 0;
@@ -66,13 +71,83 @@ int anyCamAnalysis(AnalyzerUnit *A, Run *run)
 
 extern "C" {
 
-void *abh_run_new() { return new Run(); }
+void *abh_run_new()
+{
+    Run *r = new Run();
+    r->mem = new MemParser();
+    r->parser = r->mem;
+    return r;
+}
+
+// kind 0: directory tree (RawParser), 1: zip archive (ZipParser); NULL if the source cannot be opened
+void *abh_run_open(int kind, const char *runFolder, const char *imageFolder, const char *imageFormat)
+{
+    try {
+        Run *r = new Run();
+        if (kind == 0)
+            r->parser = new RawParser(runFolder, imageFolder, imageFormat);
+        else
+            r->parser = new ZipParser(runFolder, imageFolder, imageFormat);
+        return r;
+    } catch (int code) {
+        return nullptr;
+    } catch (std::exception &) {
+        return nullptr;
+    }
+}
+
+// '\n'-joined list into the run's scratch string; returns its c_str (valid until the next query)
+const char *abh_run_events(void *r)
+{
+    Run *run = (Run *)r;
+    std::vector<std::string> ev;
+    run->parser->GetEventDirLists(ev);
+    std::sort(ev.begin(), ev.end(), [](const std::string &a, const std::string &b) { return std::stoi(a) < std::stoi(b); });
+    run->frames_of_last_query.clear();
+    for (auto &e : ev)
+        run->frames_of_last_query += e + "\n";
+    return run->frames_of_last_query.c_str();
+}
+const char *abh_run_frames(void *r, const char *ev, int cam)
+{
+    Run *run = (Run *)r;
+    std::vector<std::string> fr;
+    run->parser->ParseAndSortFramesInFolder(ev, cam, fr);
+    run->frames_of_last_query.clear();
+    for (auto &f : fr)
+        run->frames_of_last_query += f + "\n";
+    return run->frames_of_last_query.c_str();
+}
+// decode one frame through the parser: returns GetImage's code, fills w/h and (if cap suffices) the pixels
+int abh_run_image(void *r, const char *ev, const char *frame, uint8_t *out, int cap, int *w, int *h)
+{
+    Run *run = (Run *)r;
+    cv::Mat m;
+    int rc = run->parser->GetImage(ev, frame, m);
+    *w = m.cols;
+    *h = m.rows;
+    if (!m.empty() && (int)m.total() <= cap)
+        std::memcpy(out, m.data, m.total());
+    return rc;
+}
+int abh_imdecode(const uint8_t *data, int n, uint8_t *out, int cap, int *w, int *h)
+{
+    cv::Mat m = cv::imdecode(data, (size_t)n, 0);
+    *w = m.cols;
+    *h = m.rows;
+    if (m.empty())
+        return -1;
+    if ((int)m.total() <= cap)
+        std::memcpy(out, m.data, m.total());
+    return 0;
+}
 
 void abh_run_free(void *r)
 {
     Run *run = (Run *)r;
     for (auto &kv : run->trainers)
         delete kv.second;
+    delete run->parser;
     delete run;
     abub::DeviceContext::releaseThread();
 }
@@ -90,7 +165,9 @@ int abh_run_add_event(void *r, const char *ev, int cam, const uint8_t *frames, i
         }
         v.push_back(m);
     }
-    run->parser.AddFrames(ev, cam, v);
+    if (!run->mem)
+        return -1;
+    run->mem->AddFrames(ev, cam, v);
     return 0;
 }
 
@@ -100,10 +177,10 @@ int abh_train(void *r, int cam, int *status, int *tss, uint8_t *mu_out, uint8_t 
     Run *run = (Run *)r;
     try {
         std::vector<std::string> events;
-        run->parser.GetEventDirLists(events);
+        run->parser->GetEventDirLists(events);
         std::sort(events.begin(), events.end(), [](const std::string &a, const std::string &b) { return std::stoi(a) < std::stoi(b); });
         delete run->trainers[cam];
-        Trainer *t = new Trainer(cam, events, "", "cam%d_image%u.png", "", run->parser.clone(), false);
+        Trainer *t = new Trainer(cam, events, "", "cam%d_image%u.png", "", run->parser->clone(), false);
         run->trainers[cam] = t;
         t->MakeAvgSigmaImage(false);
         *status = t->StatusCode;
@@ -125,7 +202,7 @@ int abh_set_model(void *r, int cam, const uint8_t *mu, const uint8_t *sigma, int
     Run *run = (Run *)r;
     static unsigned long long next = 1ull << 40;
     delete run->trainers[cam];
-    Trainer *t = new Trainer(cam, {}, "", "cam%d_image%u.png", "", run->parser.clone(), false);
+    Trainer *t = new Trainer(cam, {}, "", "cam%d_image%u.png", "", run->parser->clone(), false);
     t->TrainedAvgImage.create(H, W, CV_8U);
     t->TrainedSigmaImage.create(H, W, CV_8U);
     std::memcpy(t->TrainedAvgImage.data, mu, (size_t)W * H);
@@ -149,7 +226,7 @@ int abh_analyze(void *r, const char *ev, int cam, const char *maskdir)
     Trainer *t = it->second;
     AnalyzerUnit *A = nullptr;
     try {
-        A = new L3Localizer(ev, "", cam, true, &t, maskdir ? maskdir : "", run->parser.clone());
+        A = new L3Localizer(ev, "", cam, true, &t, maskdir ? maskdir : "", run->parser->clone());
     } catch (std::exception &e) {
         run->error = e.what();
         return -100;
@@ -169,6 +246,97 @@ int abh_analyze(void *r, const char *ev, int cam, const char *maskdir)
     }
     delete A;
     return run->staged;
+}
+
+// reference main(): header once per run (AutoBubStart3.cpp:250-251)
+void abh_write_header(const char *outdir, const char *run_number, int frameOffset, int ncams)
+{
+    OutputWriter w(outdir, run_number, frameOffset, ncams);
+    w.writeHeader();
+}
+
+// reference main() loop body for one event (AutoBubStart3.cpp:352-387): a writer per event, one
+// L3Localizer per camera driven by AnyCamAnalysis, then the block is appended to abub3hs_<run>.txt
+int abh_event_to_file(void *r, const char *ev, int actualEventNumber, int ncams, const char *maskdir,
+                      const char *outdir, const char *run_number, int frameOffset)
+{
+    Run *run = (Run *)r;
+    OutputWriter writer(outdir, run_number, frameOffset, ncams);
+    std::vector<AnalyzerUnit *> analyzers;
+    for (int cam = 0; cam < ncams; ++cam) {
+        auto it = run->trainers.find(cam);
+        if (it == run->trainers.end() || !it->second)
+            return -100;
+        Trainer *t = it->second;
+        AnalyzerUnit *A = new L3Localizer(ev, "", cam, true, &t, maskdir ? maskdir : "", run->parser->clone());
+        analyzers.push_back(A);
+        // AnyCamAnalysis with staging (AutoBubStart3.cpp:87-117)
+        try {
+            do {
+                A->FindTriggerFrame(true, A->MatTrigFrame + 1);
+                if (A->okToProceed) {
+                    A->LocalizeOMatic("");
+                    if (A->okToProceed)
+                        writer.stageCameraOutput(A->BubbleList, cam, A->MatTrigFrame, actualEventNumber);
+                    else {
+                        writer.stageCameraOutputError(cam, -8, actualEventNumber);
+                        break;
+                    }
+                } else {
+                    writer.stageCameraOutputError(cam, A->TriggerFrameIdentificationStatus, actualEventNumber);
+                    break;
+                }
+            } while (A->BubbleList.size() == 0);
+        } catch (std::exception &e) {
+            std::cout << e.what() << '\n';
+            writer.stageCameraOutputError(cam, -6, actualEventNumber);
+        }
+    }
+    writer.writeCameraOutput(); // before the analyzers (owners of the bubbles) go away
+    for (AnalyzerUnit *A : analyzers)
+        delete A;
+    return 0;
+}
+
+// writer probe for CPU unit tests: per camera a status, a trigger frame and bubbles given as descriptor
+// rows (x,y,w,h,area,radius,m00,m10,m01,cx,cy); first row of a bubble = genesis
+void abh_writer_probe(const char *outdir, const char *run_number, int frameOffset, int ncams, int event,
+                      const int *status, const int *frame0, const int *nbub, const int *ndesc, const double *desc)
+{
+    OutputWriter w(outdir, run_number, frameOffset, ncams);
+    std::vector<std::vector<bubble *>> lists(ncams);
+    int bi = 0, di = 0;
+    for (int c = 0; c < ncams; ++c) {
+        for (int k = 0; k < nbub[c]; ++k, ++bi) {
+            bubble *b = nullptr;
+            for (int d = 0; d < ndesc[bi]; ++d, ++di) {
+                const double *r = desc + 11 * (size_t)di;
+                BubbleImageFrame f;
+                f.newPosition = cv::Rect((int)r[0], (int)r[1], (int)r[2], (int)r[3]);
+                f.ContArea = r[4];
+                f.ContRadius = r[5];
+                f.moments.m00 = r[6];
+                f.moments.m10 = r[7];
+                f.moments.m01 = r[8];
+                f.MassCentres = cv::Point2f((float)r[9], (float)r[10]);
+                if (!b)
+                    b = new bubble(f);
+                else {
+                    b->lockThisIteration = false;
+                    *b << f;
+                }
+            }
+            lists[c].push_back(b);
+        }
+        if (status[c] == 0)
+            w.stageCameraOutput(lists[c], c, frame0[c], event);
+        else
+            w.stageCameraOutputError(c, status[c], event);
+    }
+    w.writeCameraOutput();
+    for (auto &l : lists)
+        for (bubble *b : l)
+            delete b;
 }
 
 int abh_last_trig(void *r) { return ((Run *)r)->trig; }

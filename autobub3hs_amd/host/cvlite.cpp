@@ -1,31 +1,32 @@
-// cvlite.cpp -- BMP reader for the mask images (cam_masks/<series>/camN[_bellows]_mask.bmp are 1-bit
-// or 8-bit uncompressed BMPs).  Grey conversion of palette / BGR pixels uses OpenCV's fixed-point
-// BGR2GRAY weights (B 1868, G 9617, R 4899, >> 14).
+// cvlite.cpp -- grey decoders for the two container formats PICO data comes in: PNG (camera frames,
+// bellows templates) and BMP (older series, mask files).  Decode only; all image processing is on the GPU.
+//  * BGR/palette -> grey for BMP uses OpenCV's fixed-point BGR2GRAY weights (B 1868, G 9617, R 4899, >> 14).
+//  * PNG colour -> grey follows libpng's png_set_rgb_to_gray(0.299, 0.587) as OpenCV's PNG reader requests it:
+//    (r*9797 + g*19234 + b*3737 + 16384) >> 15.  Both are the identity on grey palettes / grey pixels, which is
+//    what PICO frames are (palette-grey PNG); exactness on coloured inputs is unpinned (no OpenCV here).
 #include "cvlite.hpp"
 
 #ifndef ABUB_USE_OPENCV
 #include <cstdio>
+#include <cstring>
 #include <vector>
+
+#include <zlib.h>
 
 namespace cv {
 
-static inline uchar grey(int b, int g, int r) { return (uchar)((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14); }
+static inline uchar bgr2grey(int b, int g, int r) { return (uchar)((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14); }
+static inline uchar png_rgb2grey(int r, int g, int b) { return (uchar)((r * 9797 + g * 19234 + b * 3737 + 16384) >> 15); }
 
-Mat imread(const std::string &path, int)
+// ---------------------------------------------------------------------------------------------
+// BMP
+// ---------------------------------------------------------------------------------------------
+static Mat decodeBMP(const uchar *buf, size_t size)
 {
     Mat out;
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f)
-        return out;
-    std::vector<uchar> buf;
-    uchar tmp[65536];
-    size_t n;
-    while ((n = fread(tmp, 1, sizeof tmp, f)) > 0)
-        buf.insert(buf.end(), tmp, tmp + n);
-    fclose(f);
     auto u16 = [&](size_t o) { return (unsigned)buf[o] | ((unsigned)buf[o + 1] << 8); };
     auto u32 = [&](size_t o) { return (unsigned)buf[o] | ((unsigned)buf[o + 1] << 8) | ((unsigned)buf[o + 2] << 16) | ((unsigned)buf[o + 3] << 24); };
-    if (buf.size() < 54 || buf[0] != 'B' || buf[1] != 'M')
+    if (size < 54 || buf[0] != 'B' || buf[1] != 'M')
         return out;
     const unsigned dataOff = u32(10), hdr = u32(14);
     if (hdr < 40)
@@ -49,27 +50,181 @@ Mat imread(const std::string &path, int)
         pal[i] = (uchar)i;
     if (bpp <= 8) {
         size_t po = 14 + hdr;
-        for (unsigned i = 0; i < ncol && po + 4 * i + 3 < buf.size(); ++i)
-            pal[i] = grey(buf[po + 4 * i], buf[po + 4 * i + 1], buf[po + 4 * i + 2]);
+        for (unsigned i = 0; i < ncol && i < 256 && po + 4 * i + 3 < size; ++i)
+            pal[i] = bgr2grey(buf[po + 4 * i], buf[po + 4 * i + 1], buf[po + 4 * i + 2]);
     }
     const size_t stride = ((size_t)w * bpp + 31) / 32 * 4;
-    if ((size_t)dataOff + stride * h > buf.size())
+    if ((size_t)dataOff + stride * h > size)
         return out;
     out.create(h, w, CV_8U);
     for (int y = 0; y < h; ++y) {
-        const uchar *src = buf.data() + dataOff + stride * (topDown ? y : h - 1 - y);
+        const uchar *src = buf + dataOff + stride * (topDown ? y : h - 1 - y);
         uchar *dst = out.ptr<uchar>(y);
         for (int x = 0; x < w; ++x) {
             switch (bpp) {
             case 1: dst[x] = pal[(src[x >> 3] >> (7 - (x & 7))) & 1]; break;
             case 4: dst[x] = pal[(src[x >> 1] >> ((x & 1) ? 0 : 4)) & 15]; break;
             case 8: dst[x] = pal[src[x]]; break;
-            case 24: dst[x] = grey(src[3 * x], src[3 * x + 1], src[3 * x + 2]); break;
-            default: dst[x] = grey(src[4 * x], src[4 * x + 1], src[4 * x + 2]); break;
+            case 24: dst[x] = bgr2grey(src[3 * x], src[3 * x + 1], src[3 * x + 2]); break;
+            default: dst[x] = bgr2grey(src[4 * x], src[4 * x + 1], src[4 * x + 2]); break;
             }
         }
     }
     return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PNG (non-interlaced)
+// ---------------------------------------------------------------------------------------------
+static inline int paeth(int a, int b, int c)
+{
+    int p = a + b - c, pa = p > a ? p - a : a - p, pb = p > b ? p - b : b - p, pc = p > c ? p - c : c - p;
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+static Mat decodePNG(const uchar *buf, size_t size)
+{
+    Mat out;
+    static const uchar sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (size < 8 + 25 || memcmp(buf, sig, 8) != 0)
+        return out;
+    auto be32 = [&](size_t o) { return ((unsigned)buf[o] << 24) | ((unsigned)buf[o + 1] << 16) | ((unsigned)buf[o + 2] << 8) | (unsigned)buf[o + 3]; };
+    unsigned w = 0, h = 0, depth = 0, ctype = 0, interlace = 0;
+    uchar pal[256][3];
+    int npal = 0;
+    std::vector<uchar> idat;
+    size_t o = 8;
+    bool haveHdr = false, end = false;
+    while (!end && o + 12 <= size) {
+        const unsigned len = be32(o);
+        const uchar *type = buf + o + 4;
+        const uchar *data = buf + o + 8;
+        if (o + 12 + (size_t)len > size)
+            return out;
+        if (!memcmp(type, "IHDR", 4) && len >= 13) {
+            w = be32(o + 8);
+            h = be32(o + 12);
+            depth = data[8];
+            ctype = data[9];
+            interlace = data[12];
+            haveHdr = true;
+        } else if (!memcmp(type, "PLTE", 4)) {
+            npal = (int)(len / 3);
+            if (npal > 256)
+                npal = 256;
+            for (int i = 0; i < npal; ++i) {
+                pal[i][0] = data[3 * i];
+                pal[i][1] = data[3 * i + 1];
+                pal[i][2] = data[3 * i + 2];
+            }
+        } else if (!memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), data, data + len);
+        } else if (!memcmp(type, "IEND", 4)) {
+            end = true;
+        }
+        o += 12 + (size_t)len;
+    }
+    if (!haveHdr || w == 0 || h == 0 || interlace != 0 || idat.empty())
+        return out;
+    int channels;
+    switch (ctype) {
+    case 0: channels = 1; break;
+    case 2: channels = 3; break;
+    case 3: channels = 1; break;
+    case 4: channels = 2; break;
+    case 6: channels = 4; break;
+    default: return out;
+    }
+    if (!(depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16))
+        return out;
+    if ((ctype == 2 || ctype == 4 || ctype == 6) && depth < 8)
+        return out;
+    if (ctype == 3 && depth == 16)
+        return out;
+    const size_t bitsPerPixel = (size_t)channels * depth;
+    const size_t rowBytes = ((size_t)w * bitsPerPixel + 7) / 8;
+    const size_t bpp = bitsPerPixel >= 8 ? bitsPerPixel / 8 : 1; // filter distance
+    std::vector<uchar> raw((rowBytes + 1) * (size_t)h);
+    uLongf rawLen = (uLongf)raw.size();
+    if (uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size()) != Z_OK || rawLen != raw.size())
+        return out;
+    out.create((int)h, (int)w, CV_8U);
+    std::vector<uchar> prev(rowBytes, 0), cur(rowBytes);
+    for (unsigned y = 0; y < h; ++y) {
+        const uchar *src = raw.data() + (rowBytes + 1) * (size_t)y;
+        const int ft = src[0];
+        ++src;
+        for (size_t i = 0; i < rowBytes; ++i) {
+            const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+            int v = src[i];
+            switch (ft) {
+            case 0: break;
+            case 1: v += a; break;
+            case 2: v += b; break;
+            case 3: v += (a + b) >> 1; break;
+            case 4: v += paeth(a, b, c); break;
+            default: out.release(); return out;
+            }
+            cur[i] = (uchar)v;
+        }
+        uchar *dst = out.ptr<uchar>((int)y);
+        for (unsigned x = 0; x < w; ++x) {
+            if (ctype == 0 || ctype == 3) {
+                unsigned v;
+                if (depth == 8)
+                    v = cur[x];
+                else if (depth == 16)
+                    v = cur[2 * x]; // high byte (16 -> 8 bit strip)
+                else {
+                    const unsigned per = 8 / depth, shift = (per - 1 - (x % per)) * depth;
+                    v = (cur[x / per] >> shift) & ((1u << depth) - 1);
+                    if (ctype == 0)
+                        v = v * 255u / ((1u << depth) - 1); // expand_gray_1_2_4_to_8
+                }
+                if (ctype == 3) {
+                    dst[x] = (int)v < npal ? png_rgb2grey(pal[v][0], pal[v][1], pal[v][2]) : 0;
+                } else
+                    dst[x] = (uchar)v;
+            } else if (ctype == 4) {
+                dst[x] = depth == 8 ? cur[2 * x] : cur[4 * x];
+            } else { // RGB / RGBA
+                const size_t step = (size_t)channels * (depth / 8), k = depth / 8;
+                dst[x] = png_rgb2grey(cur[x * step], cur[x * step + k], cur[x * step + 2 * k]);
+            }
+        }
+        prev.swap(cur);
+    }
+    return out;
+}
+
+Mat imdecode(const uchar *data, size_t size, int)
+{
+    if (size >= 8 && data[0] == 0x89 && data[1] == 'P')
+        return decodePNG(data, size);
+    if (size >= 2 && data[0] == 'B' && data[1] == 'M')
+        return decodeBMP(data, size);
+    return Mat();
+}
+
+Mat imdecode(const std::vector<uchar> &buf, int flags) { return imdecode(buf.data(), buf.size(), flags); }
+
+Mat imread(const std::string &path, int flags)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f)
+        return Mat();
+    std::vector<uchar> buf;
+    if (fseek(f, 0, SEEK_END) == 0) {
+        long n = ftell(f);
+        if (n > 0) {
+            buf.resize((size_t)n);
+            rewind(f);
+            if (fread(buf.data(), 1, buf.size(), f) != buf.size())
+                buf.clear();
+        }
+    }
+    fclose(f);
+    return buf.empty() ? Mat() : imdecode(buf, flags);
 }
 
 } // namespace cv

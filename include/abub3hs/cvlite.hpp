@@ -141,9 +141,12 @@ private:
 };
 
 enum { IMREAD_GRAYSCALE = 0 };
-// 8-bit grey decode of BMP (1/8/24/32-bit, uncompressed) files -- the mask format of
-// cam_masks/<series>/camN[_bellows]_mask.bmp (L3Localizer.cpp:980-986).  Empty Mat on failure.
+// 8-bit grey decode of PNG (grey / palette / RGB(A), 1-16 bit, non-interlaced) and BMP (1/4/8/24/32-bit,
+// uncompressed) -- the formats of PICO camera frames (RawParser.cpp:39, ZipParser.cpp:222) and of the
+// mask files cam_masks/<series>/camN[_bellows]_mask.bmp (L3Localizer.cpp:980-986).  Empty Mat on failure.
 Mat imread(const std::string &path, int flags = IMREAD_GRAYSCALE);
+Mat imdecode(const std::vector<uchar> &buf, int flags = IMREAD_GRAYSCALE);
+Mat imdecode(const uchar *data, size_t size, int flags = IMREAD_GRAYSCALE);
 
 } // namespace cv
 

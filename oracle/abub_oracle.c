@@ -14,6 +14,8 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1197,4 +1199,110 @@ uint64_t orc_bench_trigger_pass(const uint8_t *frames, int F, int W, int H, cons
     }
     free(D);
     return ck;
+}
+
+/* ======================================================================================= */
+/* PICO recon format (PICOFormatWriterV4.cpp)                                              */
+/* ======================================================================================= */
+
+typedef struct {
+    char *p;
+    int cap, n, overflow;
+} sbuf;
+
+static void sb_printf(sbuf *b, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    int room = b->cap - b->n;
+    int w = vsnprintf(b->p + b->n, room > 0 ? (size_t)room : 0, fmt, ap);
+    va_end(ap);
+    if (w < 0 || w >= room)
+        b->overflow = 1;
+    else
+        b->n += w;
+}
+
+/* writeHeader, :54-88 */
+int orc_format_header(char *out, int cap)
+{
+    sbuf b = {out, cap, 0, 0};
+    const int n = ORC_MAX_TRACK;
+    sb_printf(&b, "Output of AutoBub v3 - the automatic unified bubble finder code by Pitam, using OpenCV.\n");
+    sb_printf(&b, "run  ev  ibubimage  TotalBub4CamImg  camera  frame0  hori  vert  GenesisW  GenesisH  dZdt  dRdt  ");
+    sb_printf(&b, "TrkFrame(%d)  TrkHori(%d)  TrkVert(%d)  ", n, n, n);
+    sb_printf(&b, "TrkBubW(%d)  TrkBubH(%d)  TrkBubRadius(%d)  FakeValue\n", n, n, n);
+    sb_printf(&b, "%%12s  %%5d  %%d  %%d  %%d  %%d  %%.02f  %%.02f  %%d  %%d  %%.02f  %%.02f  ");
+    for (int j = 1; j <= n; j++)
+        sb_printf(&b, "%%d  ");
+    for (int k = 0; k < 5; k++)
+        for (int j = 1; j <= n; j++)
+            sb_printf(&b, "%%.02f  ");
+    sb_printf(&b, "%%d");
+    sb_printf(&b, "\n8\n\n\n");
+    return b.overflow ? -1 : b.n;
+}
+
+/* writeCameraOutput :287-302 + formEachBubbleOutput :132-283; std::fixed, precision 2, "  " separators */
+int orc_format_event(orc_analyzer *const *cams, const int *staged, int ncams, const char *run_number,
+                     int event, int frameOffset, char *out, int cap)
+{
+    sbuf b = {out, cap, 0, 0};
+    const int n = ORC_MAX_TRACK;
+    int ibub = 1, nBubTotal = 0;
+    for (int c = 0; c < ncams; c++)
+        nBubTotal += staged[c] != 0 ? 0 : cams[c]->nbub; /* :291-294 */
+    for (int c = 0; c < ncams; c++) {
+        const orc_analyzer *a = cams[c];
+        if (staged[c] != 0) { /* :146-174 */
+            sb_printf(&b, "%s  %d  %d  %d  %d  %d  %.2f  %.2f  %d  %d", run_number, event, 0, 0, c, staged[c], 0.0, 0.0, 0, 0);
+            sb_printf(&b, "  %.2f  %.2f  ", 0.0, 0.0);
+            for (int j = 1; j <= n; j++)
+                sb_printf(&b, "%d  ", 0);
+            for (int j = 1; j <= 5 * n; j++)
+                sb_printf(&b, "%.2f  ", 0.0);
+            sb_printf(&b, "1  \n");
+            continue;
+        }
+        for (int i = 0; i < a->nbub; i++) { /* :180-276 */
+            const orc_bubble *bb = &a->bubbles[i];
+            int frame0 = a->MatTrigFrame + frameOffset; /* :184 */
+            float width = (float)bb->desc[0].w, height = (float)bb->desc[0].h;
+            float x = bb->desc[0].cx, y = bb->desc[0].cy;
+            float dzdt = orc_get_bubble_dzdt(a, i), drdt = orc_get_bubble_drdt(a, i);
+            int tracked = bb->n_desc - 1;
+            int excess = n > tracked ? n - tracked : 0;
+            sb_printf(&b, "%s  %d  %d  %d  %d  ", run_number, event, ibub + i, nBubTotal, c);
+            sb_printf(&b, "%d  ", frame0);
+            sb_printf(&b, "%.2f  %.2f  %d  %d  %.2f  %.2f  ", (double)x, (double)y, (int)width, (int)height, (double)dzdt,
+                      (double)drdt);
+            for (int j = 1; j <= tracked; j++)
+                sb_printf(&b, "%d  ", frame0 + j);
+            for (int j = 0; j < excess; j++)
+                sb_printf(&b, "%d  ", frame0 + tracked + j);
+            for (int j = 1; j <= tracked; j++)
+                sb_printf(&b, "%.2f  ", (double)bb->desc[j].cx);
+            for (int j = 0; j < excess; j++)
+                sb_printf(&b, "%d  ", -1);
+            for (int j = 1; j <= tracked; j++)
+                sb_printf(&b, "%.2f  ", (double)bb->desc[j].cy);
+            for (int j = 0; j < excess; j++)
+                sb_printf(&b, "%d  ", -1);
+            for (int j = 1; j <= tracked; j++)
+                sb_printf(&b, "%d  ", bb->desc[j].w);
+            for (int j = 0; j < excess; j++)
+                sb_printf(&b, "%d  ", -1);
+            for (int j = 1; j <= tracked; j++)
+                sb_printf(&b, "%d  ", bb->desc[j].h);
+            for (int j = 0; j < excess; j++)
+                sb_printf(&b, "%d  ", -1);
+            for (int j = 1; j <= tracked; j++)
+                sb_printf(&b, "%.2f  ", bb->desc[j].radius);
+            for (int j = 0; j < excess; j++)
+                sb_printf(&b, "%d  ", -1);
+            sb_printf(&b, "1  \n");
+        }
+        ibub += a->nbub;
+    }
+    return b.overflow ? -1 : b.n;
 }

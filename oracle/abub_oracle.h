@@ -136,6 +136,13 @@ float orc_get_bubble_drdt(const orc_analyzer *a, int b); /* bubble::dRdT bubble.
 int orc_get_sig_trace(const orc_analyzer *a, double *sig, int cap);
 int orc_get_pixcount_len(const orc_analyzer *a, int bin);
 
+/* PICO recon format, PICOFormatWriter/PICOFormatWriterV4.cpp: header :54-88; one event block :132-302
+ * (cams[c] already analysed with orc_any_cam_analysis, staged[c] its return value).  Returns the number
+ * of bytes written (excluding the terminating NUL), or -1 if cap is too small. */
+int orc_format_header(char *out, int cap);
+int orc_format_event(orc_analyzer *const *cams, const int *staged, int ncams, const char *run_number,
+                     int event, int frameOffset, char *out, int cap);
+
 /* Timed CPU-baseline helper for bench.py: ProcessFrame + hist256 over frames first..first+count-1
  * of a [F][H][W] stack with ref = frame[max(i-ref_offset,0)]; returns a checksum of the histograms. */
 uint64_t orc_bench_trigger_pass(const uint8_t *frames, int F, int W, int H, const uint8_t *sigma,

@@ -92,6 +92,9 @@ def lib():
     L.orc_get_bubble_drdt.restype = C.c_float
     L.orc_get_sig_trace.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
     L.orc_get_pixcount_len.argtypes = [C.c_void_p, C.c_int]
+    L.orc_format_header.argtypes = [C.c_char_p, C.c_int]
+    L.orc_format_event.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_int, C.c_int,
+                                   C.c_char_p, C.c_int]
     L.orc_bench_trigger_pass.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int,
                                          C.c_int, _u32p]
     L.orc_bench_trigger_pass.restype = C.c_uint64
@@ -296,3 +299,21 @@ def bench_trigger_pass(frames, sigma, ref_offset, first, count, want_hists=False
     ck = lib().orc_bench_trigger_pass(_p(frames), F, W, H, _p(sigma), ref_offset, first, count,
                                       hists.ctypes.data_as(_u32p) if want_hists else None)
     return int(ck), hists
+
+
+def format_header():
+    buf = C.create_string_buffer(1 << 14)
+    n = lib().orc_format_header(buf, len(buf))
+    assert n >= 0
+    return buf.raw[:n].decode()
+
+
+def format_event(analyzers, staged, run_number, event, frame_offset):
+    """analyzers: list of Analyzer (one per camera, already through any_cam_analysis)."""
+    n = len(analyzers)
+    hs = (C.c_void_p * n)(*[a._h for a in analyzers])
+    st = (C.c_int * n)(*staged)
+    buf = C.create_string_buffer(1 << 20)
+    w = lib().orc_format_event(hs, st, n, run_number.encode(), int(event), int(frame_offset), buf, len(buf))
+    assert w >= 0
+    return buf.raw[:w].decode()

@@ -1,0 +1,187 @@
+"""Frame ingestion (scope row 8f #2): PNG/BMP grey decode and the Raw / Zip parsers, checked on CPU against
+Pillow decodes and python's zipfile; plus (GPU) a run read from disk analysed exactly like the same run fed
+from memory."""
+import io
+import os
+import struct
+import zipfile
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from autobub3hs_amd import host, synth
+
+rng = np.random.RandomState(42)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    host.build()
+
+
+def png_bytes(img, mode="L", **kw):
+    b = io.BytesIO()
+    im = Image.fromarray(img, mode="L")
+    if mode == "P":
+        im = im.convert("P")  # grey palette
+    elif mode == "RGB":
+        im = im.convert("RGB")
+    elif mode == "I;16":
+        im = Image.fromarray(img.astype(np.uint16) * 257)
+    elif mode == "1":
+        im = Image.fromarray(img > 127)
+    im.save(b, format="PNG", **kw)
+    return b.getvalue()
+
+
+@pytest.mark.parametrize("shape", [(37, 53), (64, 1280), (5, 1)])
+def test_png_decode_matches_pillow(shape):
+    img = rng.randint(0, 256, shape).astype(np.uint8)
+    img[: shape[0] // 2] = np.sort(img[: shape[0] // 2], axis=1)  # smoother rows: exercises filter types
+    for mode in ("L", "P", "RGB", "I;16", "1"):
+        for level in (0, 6, 9):
+            data = png_bytes(img, mode, compress_level=level)
+            got = host.imdecode(data)
+            if mode == "1":
+                exp = ((img > 127) * 255).astype(np.uint8)
+            else:
+                exp = img
+            assert got is not None and np.array_equal(got, exp), (mode, level)
+    assert host.imdecode(b"not an image") is None
+    assert host.imdecode(png_bytes(img)[:50]) is None  # truncated
+
+
+def test_bmp_decode_matches_pillow():
+    img = rng.randint(0, 256, (33, 47)).astype(np.uint8)
+    for mode in ("L", "P", "RGB", "1"):
+        b = io.BytesIO()
+        im = Image.fromarray(img)
+        if mode == "1":
+            im = Image.fromarray(img > 127)
+        elif mode != "L":
+            im = im.convert(mode)
+        im.save(b, format="BMP")
+        got = host.imdecode(b.getvalue())
+        exp = ((img > 127) * 255).astype(np.uint8) if mode == "1" else img
+        assert np.array_equal(got, exp), mode
+
+
+REF = "/root/reference/cam_masks/40l-19"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference sample images are not on this machine")
+def test_reference_sample_frames_and_masks_decode_like_pillow():
+    for name in sorted(os.listdir(REF)):
+        if not name.endswith((".png", ".bmp")):
+            continue
+        data = open(os.path.join(REF, name), "rb").read()
+        got = host.imdecode(data, cap=1 << 23)
+        exp = np.array(Image.open(os.path.join(REF, name)).convert("L"))
+        assert got is not None and got.shape == exp.shape, name
+        assert np.array_equal(got, exp), name
+
+
+def make_run_dir(root, W=96, H=64, F=12, nev=3, ncams=2, fmt="png"):
+    frames = {}
+    run_id = "20200925_1"
+    rd = os.path.join(root, run_id)
+    for e in range(nev):
+        for c in range(ncams):
+            spec = synth.random_spec(W, H, F, 300 + e, c, margin=10)
+            st = synth.render_event(W, H, spec, 300 + e, c)
+            d = os.path.join(rd, str(e), "Images")
+            os.makedirs(d, exist_ok=True)
+            for k in range(F):
+                name = f"cam{c}_image{30 + k}.{fmt}"
+                Image.fromarray(st[k]).save(os.path.join(d, name))
+                frames[(e, c, name)] = st[k]
+    with open(os.path.join(rd, run_id + ".txt"), "w") as f:
+        for e in range(nev):
+            f.write(f"{run_id} {e} a b c d e f g h i\n")
+    os.makedirs(os.path.join(rd, "9", "Images"))  # an event directory the run file does not list
+    return rd, frames
+
+
+def zip_run(rd, path, compress):
+    root = os.path.dirname(rd)
+    with zipfile.ZipFile(path, "w", compression=compress, allowZip64=True) as z:
+        for dp, dn, fn in os.walk(rd):
+            rel = os.path.relpath(dp, root)
+            z.writestr(rel + "/", b"")
+            for f in sorted(fn):
+                z.write(os.path.join(dp, f), os.path.join(rel, f))
+
+
+@pytest.mark.parametrize("compress", [zipfile.ZIP_STORED, zipfile.ZIP_DEFLATED])
+def test_raw_and_zip_parsers_agree(tmp_path, compress):
+    rd, frames = make_run_dir(str(tmp_path))
+    raw = host.Run("raw", rd + "/", "Images")
+    zpath = os.path.join(str(tmp_path), "run.zip")
+    zip_run(rd, zpath, compress)
+    zp = host.Run("zip", zpath, "Images")
+    assert raw.events() == ["0", "1", "2", "9"]
+    assert zp.events() == ["0", "1", "2", "9"]
+    for e in range(3):
+        for c in range(2):
+            fr = raw.frames(e, c)
+            assert fr == sorted(n for (ee, cc, n) in frames if ee == e and cc == c)  # lexicographic
+            assert zp.frames(e, c) == fr
+            for name in fr[:3]:
+                rc1, im1 = raw.image(e, name)
+                rc2, im2 = zp.image(e, name)
+                assert rc1 == 1 and rc2 == 1
+                assert np.array_equal(im1, frames[(e, c, name)]) and np.array_equal(im2, frames[(e, c, name)])
+    assert raw.image(0, "cam0_image999.png")[0] == 0   # RawParser: 0 = empty (never -1)
+    assert zp.image(0, "cam0_image999.png")[0] == -1   # ZipParser: -1 = missing
+    with pytest.raises(RuntimeError):
+        host.Run("zip", os.path.join(str(tmp_path), "nope.zip"), "Images")
+    raw.close()
+    zp.close()
+
+
+def test_zip64_archive(tmp_path):
+    # force zip64 records for a small archive: extra fields + zip64 EOCD must be parsed
+    rd, frames = make_run_dir(str(tmp_path), nev=1, ncams=1, F=4)
+    zpath = os.path.join(str(tmp_path), "z64.zip")
+    root = os.path.dirname(rd)
+    with zipfile.ZipFile(zpath, "w", zipfile.ZIP_DEFLATED, allowZip64=True) as z:
+        for dp, dn, fn in os.walk(rd):
+            rel = os.path.relpath(dp, root)
+            z.writestr(rel + "/", b"")
+            for f in sorted(fn):
+                with z.open(zipfile.ZipInfo(os.path.join(rel, f)), "w", force_zip64=True) as dst:
+                    dst.write(open(os.path.join(dp, f), "rb").read())
+    zp = host.Run("zip", zpath, "Images")
+    fr = zp.frames(0, 0)
+    assert len(fr) == 4
+    rc, im = zp.image(0, fr[0])
+    assert rc == 1 and np.array_equal(im, frames[(0, 0, fr[0])])
+    zp.close()
+
+
+@pytest.mark.gpu
+def test_run_from_disk_equals_run_from_memory(tmp_path, oracle):
+    W, H, F = 320, 128, 20
+    rd, frames = make_run_dir(str(tmp_path), W=W, H=H, F=F, nev=4, ncams=1)
+    zpath = os.path.join(str(tmp_path), "run.zip")
+    zip_run(rd, zpath, zipfile.ZIP_DEFLATED)
+    results = []
+    for kind, src in (("raw", rd + "/"), ("zip", zpath)):
+        run = host.Run(kind, src, "Images")
+        st, tss, mu, sg = run.train(0, shape=(H, W))
+        assert st == 0 and tss == 2 * 4  # events 0..3 train; the frame-less event 9 is skipped (Trainer.cpp:271-274)
+        out = [run.analyze(e, 0)[:3] for e in range(4)]
+        results.append((tss, mu, sg, out))
+        run.close()
+    assert results[0][0] == results[1][0]
+    assert np.array_equal(results[0][1], results[1][1]) and np.array_equal(results[0][2], results[1][2])
+    assert repr(results[0][3]) == repr(results[1][3])  # repr: NaN-safe (untracked bubbles have dZdt = NaN)
+    tss, mu, sg, out = results[0]
+    for e in range(4):
+        names = sorted(n for (ee, cc, n) in frames if ee == e)
+        st = np.stack([frames[(e, 0, n)] for n in names])
+        a = oracle.Analyzer(st, mu, sg, tss)
+        ref = a.any_cam_analysis()
+        a.close()
+        assert out[e][0] == ref[0] and out[e][1] == ref[1]
