@@ -1,0 +1,242 @@
+// abub3hs_main.cpp -- command-line driver with the reference's argument surface and run flow
+// (AutoBubStart3.cpp:127-405): -d data_dir -r run_ID -o out_dir [-z] [-c mask_dir] [-m] [-D series] [-e event]
+// [--debug code]; per-series image naming / frameOffset / camera count (:220-245); header, event list, training
+// (-7 rows if it fails), event loop with ordered output, -5 if the run cannot be read.  boost::program_options and
+// OpenMP are replaced by a small parser and a std::thread pool (ABUB_THREADS, default min(16, cores)).
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "AlgorithmTraining/Trainer.hpp"
+#include "BubbleLocalizer/L3Localizer.hpp"
+#include "PICOFormatWriter/PICOFormatWriterV4.hpp"
+#include "ParseFolder/RawParser.hpp"
+#include "ParseFolder/ZipParser.hpp"
+#include "driver.hpp"
+
+static std::string usage()
+{
+    return "Usage: abub3hs [-hzme] [-D data_series] [-c cam_mask_dir] [--debug code] -d data_dir -r run_ID -o out_dir\n"
+           "Run the AutoBub3hs bubble finding algorithm on a PICO run (MI355X hot path)\n\n"
+           "Required arguments:\n"
+           "  -d, --data_dir = Dir\t\tpath to the directory in which the run folder/file is stored\n"
+           "  -r, --run_id = Str\t\trun ID, formatted as YYYYMMDD_*\n"
+           "  -o, --out_dir = Dir\t\tdirectory to write the output file to\n\n"
+           "Optional arguments:\n"
+           "  -h, --help\t\t\tgive this help message\n"
+           "  -z, --zip\t\t\tindicate the run is stored as a zip file; otherwise assumed to be in a directory\n"
+           "  -c, --cam_mask_dir = Dir\tdirectory containing the camera mask images\n"
+           "  -m, --mask_check\t\tuse camera masks in default directory. Not needed if directory specified\n"
+           "  -D, --data_series = Str\tname of the data series, e.g. 40l-19, 30l-16, etc.\n"
+           "  -e, --event = Int\t\tspecify a single event to process. Mostly just useful for debugging and testing\n"
+           "  --debug = Int\t\t\t3 digit int; eg: 101: first digit = localizer debug; second digit = multithread off; third digit = analyzer debug\n";
+}
+
+static bool eventNameOrderSort(const std::string &a, const std::string &b) { return std::stoi(a) < std::stoi(b); }
+
+int main(int argc, char **argv)
+{
+    std::string dataLoc, run_number, out_dir, mask_dir, data_series;
+    int event_user = -1, debug_mode = 0;
+    bool zipped = false, mask_check = false, help = argc == 1;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i], v;
+        auto value = [&](std::string &dst) {
+            size_t eq = a.find('=');
+            if (a.rfind("--", 0) == 0 && eq != std::string::npos)
+                dst = a.substr(eq + 1);
+            else if (i + 1 < argc)
+                dst = argv[++i];
+        };
+        auto is = [&](const char *s, const char *l) { return a == s || a == l || a.rfind(std::string(l) + "=", 0) == 0; };
+        if (is("-h", "--help"))
+            help = true;
+        else if (is("-z", "--zip"))
+            zipped = true;
+        else if (is("-m", "--mask_check"))
+            mask_check = true;
+        else if (is("-d", "--data_dir"))
+            value(dataLoc);
+        else if (is("-r", "--run_num") || a == "--run_id")
+            value(run_number);
+        else if (is("-o", "--out_dir"))
+            value(out_dir);
+        else if (is("-c", "--cam_mask_dir"))
+            value(mask_dir);
+        else if (is("-D", "--data_series"))
+            value(data_series);
+        else if (is("-e", "--event")) {
+            value(v);
+            event_user = atoi(v.c_str());
+        } else if (a.rfind("--debug", 0) == 0) {
+            value(v);
+            debug_mode = atoi(v.c_str());
+        } else {
+            std::cerr << "unrecognised option '" << a << "'" << std::endl;
+            return -1;
+        }
+    }
+    if (help) {
+        std::cout << usage() << std::endl;
+        return 1;
+    }
+    if (dataLoc.empty() || run_number.empty() || out_dir.empty()) {
+        std::cerr << "Insufficient required arguments; use \"autobub3hs -h\" to view required arguments" << std::endl;
+        return -1;
+    }
+    printf("This is AutoBub v3, the automatic unified bubble finder code for all chambers\n");
+
+    std::string this_path = argv[0];
+    std::string abub_dir = this_path.substr(0, this_path.find_last_of("/") + 1);
+    if (mask_check && mask_dir == "")
+        mask_dir = abub_dir + "cam_masks/" + data_series;
+    else if (!mask_check && mask_dir == "")
+        std::cout << "Not performing mask check on this run." << std::endl;
+
+    std::string eventDir = dataLoc + "/" + run_number + "/";
+    if (out_dir[out_dir.length() - 1] != '/')
+        out_dir += "/";
+
+    // how the different experiments stored their images (AutoBubStart3.cpp:216-245)
+    std::string imageFormat, imageFolder;
+    int frameOffset, numCams;
+    if (data_series == "01l-21" || data_series == "2l-16") {
+        imageFormat = "cam%dimage %u.bmp";
+        imageFolder = "/";
+        frameOffset = 0;
+        numCams = 2;
+    } else if (data_series == "40l-19") {
+        imageFormat = "cam%d_image%u.png";
+        imageFolder = "/Images/";
+        frameOffset = 30;
+        numCams = run_number >= "20200713_7" ? 4 : 2;
+        if (run_number < "20200501_1")
+            frameOffset = 20;
+    } else {
+        imageFormat = "cam%d_image%u.png";
+        imageFolder = "/Images/";
+        frameOffset = 30;
+        numCams = 4;
+    }
+    if (const char *nc = getenv("ABUB_NUM_CAMS")) // synthetic runs with fewer cameras
+        numCams = atoi(nc);
+
+    int nthreads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char *t = getenv("ABUB_THREADS"))
+        nthreads = std::max(1, atoi(t));
+    if (debug_mode % 100 / 10)
+        nthreads = 1;
+
+    OutputWriter *header = new OutputWriter(out_dir, run_number, frameOffset, numCams);
+    header->writeHeader();
+
+    std::vector<std::string> EventList;
+    Parser *FileParser = nullptr;
+    try {
+        if (zipped)
+            FileParser = new ZipParser(eventDir, imageFolder, imageFormat);
+        else
+            FileParser = new RawParser(eventDir, imageFolder, imageFormat);
+        FileParser->GetEventDirLists(EventList);
+    } catch (...) {
+        std::cout << "Failed to read the images from run " << run_number << ". Autobub cannot continue.\n";
+        for (int icam = 0; icam < numCams; icam++)
+            header->stageCameraOutputError(icam, -5, -1);
+        header->writeCameraOutput();
+        return -5;
+    }
+    std::sort(EventList.begin(), EventList.end(), eventNameOrderSort);
+
+    printf("**Starting training. AutoBub is in learn mode**\n");
+    std::vector<Trainer *> Trainers;
+    for (int icam = 0; icam < numCams; icam++)
+        Trainers.push_back(new Trainer(icam, EventList, eventDir, imageFormat, imageFolder, FileParser->clone(), debug_mode / 100));
+    {
+        std::vector<std::thread> th; // one thread per camera, like `#pragma omp parallel for` (:304-307)
+        for (int icam = 0; icam < numCams; icam++)
+            th.emplace_back([&, icam]() {
+                try {
+                    Trainers[icam]->MakeAvgSigmaImage(false);
+                } catch (std::exception &e) {
+                    std::cout << e.what() << '\n';
+                    Trainers[icam]->StatusCode = -7;
+                }
+            });
+        for (auto &t : th)
+            t.join();
+    }
+    bool succeeded = true;
+    for (Trainer *t : Trainers)
+        if (t->StatusCode)
+            succeeded = false;
+    if (!succeeded) {
+        std::cout << "Failed to train on images from run " << run_number << ". Autobub cannot continue.\n";
+        for (size_t evi = 0; evi < EventList.size(); evi++) {
+            for (int icam = 0; icam < numCams; icam++)
+                header->stageCameraOutputError(icam, -7, atoi(EventList[evi].c_str()));
+            header->writeCameraOutput();
+        }
+        return -7;
+    }
+    printf("***Training complete. AutoBub is now in detect mode***\n");
+    delete header;
+
+    // events in parallel, output appended in event order (the `ordered` clause :380-383)
+    std::cout << "Total threads: " << nthreads << std::endl;
+    std::atomic<int> next{0};
+    std::mutex turnMutex;
+    std::condition_variable turnCv;
+    int turn = 0;
+    auto worker = [&]() {
+        for (;;) {
+            const int evi = next.fetch_add(1);
+            if (evi >= (int)EventList.size())
+                break;
+            const bool skip = event_user >= 0 && evi != event_user; // compares the loop index, like upstream (:350)
+            OutputWriter *out = nullptr;
+            std::vector<AnalyzerUnit *> Analyzers;
+            if (!skip) {
+                out = new OutputWriter(out_dir, run_number, frameOffset, numCams);
+                const std::string imageDir = eventDir + EventList[evi] + "/Images/";
+                const int actualEventNumber = atoi(EventList[evi].c_str());
+                for (int icam = 0; icam < numCams; icam++) {
+                    Analyzers.push_back(new L3Localizer(EventList[evi], imageDir, icam, debug_mode / 100 ? false : true,
+                                                        &Trainers[icam], mask_dir, FileParser->clone()));
+                    abub::AnyCamAnalysis(Analyzers[icam], icam, debug_mode % 10 ? false : true, out, out_dir, actualEventNumber);
+                }
+            }
+            {
+                std::unique_lock<std::mutex> lock(turnMutex);
+                turnCv.wait(lock, [&] { return turn == evi; });
+                if (out)
+                    out->writeCameraOutput();
+                ++turn;
+            }
+            turnCv.notify_all();
+            delete out;
+            for (AnalyzerUnit *A : Analyzers)
+                delete A;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; ++t)
+            th.emplace_back(worker);
+        for (auto &t : th)
+            t.join();
+    }
+    printf("run complete.\n");
+    for (Trainer *t : Trainers)
+        delete t;
+    delete FileParser;
+    printf("AutoBub done analyzing this run. Thank you.\n");
+    return 0;
+}

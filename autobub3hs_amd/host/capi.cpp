@@ -18,6 +18,7 @@
 #include "ParseFolder/RawParser.hpp"
 #include "ParseFolder/ZipParser.hpp"
 #include "devctx.hpp"
+#include "driver.hpp"
 #include "hostlogic.hpp"
 
 namespace {
@@ -270,27 +271,7 @@ int abh_event_to_file(void *r, const char *ev, int actualEventNumber, int ncams,
         Trainer *t = it->second;
         AnalyzerUnit *A = new L3Localizer(ev, "", cam, true, &t, maskdir ? maskdir : "", run->parser->clone());
         analyzers.push_back(A);
-        // AnyCamAnalysis with staging (AutoBubStart3.cpp:87-117)
-        try {
-            do {
-                A->FindTriggerFrame(true, A->MatTrigFrame + 1);
-                if (A->okToProceed) {
-                    A->LocalizeOMatic("");
-                    if (A->okToProceed)
-                        writer.stageCameraOutput(A->BubbleList, cam, A->MatTrigFrame, actualEventNumber);
-                    else {
-                        writer.stageCameraOutputError(cam, -8, actualEventNumber);
-                        break;
-                    }
-                } else {
-                    writer.stageCameraOutputError(cam, A->TriggerFrameIdentificationStatus, actualEventNumber);
-                    break;
-                }
-            } while (A->BubbleList.size() == 0);
-        } catch (std::exception &e) {
-            std::cout << e.what() << '\n';
-            writer.stageCameraOutputError(cam, -6, actualEventNumber);
-        }
+        abub::AnyCamAnalysis(A, cam, true, &writer, "", actualEventNumber);
     }
     writer.writeCameraOutput(); // before the analyzers (owners of the bubbles) go away
     for (AnalyzerUnit *A : analyzers)
