@@ -44,6 +44,8 @@ SIGNATURES = {
     "abub_posttrig_compact_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp]),
     "abub_pairs_group_dev": (_i, [_vp, _vp, C.c_uint32, _i, _vp, _vp, _vp, _vp, _vp]),
     "abub_fg_compact_pairs_dev": (_i, [_vp, _i, _i, _i, _vp, _vp, C.c_uint32, _vp, _vp]),
+    "abub_match_ccorr_dev": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    "abub_subsat_hist_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "abub_ctx_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i]),
     "abub_ctx_destroy": (None, [_vp]),
     "abub_ctx_train": (_i, [_vp, C.POINTER(_vp), _i, _vp, _vp]),
@@ -55,6 +57,9 @@ SIGNATURES = {
     "abub_ctx_diff_frame_roi": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "abub_ctx_posttrig": (_i, [_vp, _i, _vp, _vp]),
     "abub_ctx_foreground": (_i, [_vp, _i, _vp, _i, C.POINTER(_i)]),
+    "abub_ctx_match_template": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
+    "abub_ctx_subtract_image": (_i, [_vp, _vp, _vp]),
+    "abub_ctx_set_image": (_i, [_vp, _vp]),
     "abub_ctx_fetch_image": (_i, [_vp, _vp]),
 }
 

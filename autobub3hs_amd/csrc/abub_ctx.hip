@@ -309,6 +309,67 @@ extern "C" int abub_ctx_foreground(abub_ctx *c, int thr, uint32_t *idx_out, int 
     return cnt > (uint32_t)dcap ? ABUB_E_OVERFLOW : ABUB_OK;
 }
 
+extern "C" int abub_ctx_match_template(abub_ctx *c, int i, const uint8_t *tmpl, int tw, int th,
+                                       unsigned long long *num_out, unsigned long long *wsum2_out)
+{
+    if (!c || !tmpl || !num_out || !wsum2_out || i < 0 || i >= c->F || tw <= 0 || th <= 0 || tw > c->W || th > c->H)
+        return cfail(ABUB_E_INVALID, "abub_ctx_match_template: bad arguments");
+    CCHK(hipSetDevice(c->device));
+    const size_t n = (size_t)(c->W - tw + 1) * (c->H - th + 1);
+    uint8_t *d_t = nullptr;
+    unsigned long long *d_num = nullptr, *d_w = nullptr;
+    CCHK(hipMalloc((void **)&d_t, (size_t)tw * th));
+    CCHK(hipMalloc((void **)&d_num, n * 8));
+    CCHK(hipMalloc((void **)&d_w, n * 8));
+    int rc = ABUB_OK;
+    hipError_t e = hipMemcpyAsync(d_t, tmpl, (size_t)tw * th, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+        rc = abub_match_ccorr_dev(c->d_frames + (size_t)i * c->P, c->W, c->H, d_t, tw, th, d_num, d_w, c->stream);
+    if (e == hipSuccess && rc == ABUB_OK)
+        e = hipMemcpyAsync(num_out, d_num, n * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && rc == ABUB_OK)
+        e = hipMemcpyAsync(wsum2_out, d_w, n * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_t);
+    (void)hipFree(d_num);
+    (void)hipFree(d_w);
+    if (e != hipSuccess)
+        return cfail(ABUB_E_HIP, "abub_ctx_match_template", e);
+    return rc;
+}
+
+extern "C" int abub_ctx_subtract_image(abub_ctx *c, const uint8_t *sub, uint32_t *hist_out)
+{
+    if (!c || !sub)
+        return cfail(ABUB_E_INVALID, "abub_ctx_subtract_image: bad arguments");
+    CCHK(hipSetDevice(c->device));
+    uint8_t *d_sub = nullptr;
+    CCHK(hipMalloc((void **)&d_sub, c->P));
+    hipError_t e = hipMemcpyAsync(d_sub, sub, c->P, hipMemcpyHostToDevice, c->stream);
+    int rc = ABUB_OK;
+    if (e == hipSuccess)
+        rc = abub_subsat_hist_dev(c->d_img, d_sub, c->W, c->H, c->d_hist, c->stream);
+    if (e == hipSuccess && rc == ABUB_OK)
+        rc = finish_image(c, nullptr, hist_out);
+    else
+        (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d_sub);
+    if (e != hipSuccess)
+        return cfail(ABUB_E_HIP, "abub_ctx_subtract_image", e);
+    return rc;
+}
+
+extern "C" int abub_ctx_set_image(abub_ctx *c, const uint8_t *img)
+{
+    if (!c || !img)
+        return cfail(ABUB_E_INVALID, "abub_ctx_set_image: bad arguments");
+    CCHK(hipSetDevice(c->device));
+    CCHK(hipMemcpyAsync(c->d_img, img, c->P, hipMemcpyHostToDevice, c->stream));
+    CCHK(hipStreamSynchronize(c->stream));
+    return ABUB_OK;
+}
+
 extern "C" int abub_ctx_fetch_image(abub_ctx *c, uint8_t *out)
 {
     if (!c || !out)

@@ -1398,3 +1398,106 @@ extern "C" int abub_pairs_group_dev(const uint32_t *pairs, const uint32_t *count
     HIPCHK(hipGetLastError());
     return ABUB_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Bellows veto support (L3Localizer::TrackAFeature, L3Localizer.cpp:473-543): raw terms of
+// cv::matchTemplate(CV_TM_CCORR_NORMED) -- for every placement (x,y) of the template the exact integer
+// cross-correlation sum(T*I) and window energy sum(I*I).  The double-precision normalisation, the min-max
+// normalise and the sub-pixel centre of mass are host work on the (small) result matrix.
+// One thread = 4 adjacent x placements (sliding 4-byte window), one workgroup row = one result row.
+// Per template row the partial sums stay in u32 (<= 2048*65025*... guarded by tw <= 4096), then widen.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_match_ccorr(const uint8_t *__restrict__ img, int W, int H,
+                                                    const uint8_t *__restrict__ tmpl, int tw, int th, int rw, int rh,
+                                                    unsigned long long *__restrict__ num,
+                                                    unsigned long long *__restrict__ wsum2)
+{
+    const int y = blockIdx.y;
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (x0 >= rw)
+        return;
+    unsigned long long acc[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
+    for (int r = 0; r < th; r++) {
+        const uint8_t *irow = img + (size_t)(y + r) * W;
+        const uint8_t *trow = tmpl + (size_t)r * tw;
+        uint32_t a[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+        // window bytes f[k] = I(x0 + c + k); positions beyond the row end are clamped (their results are discarded)
+        uint32_t f0 = irow[min(x0, W - 1)], f1 = irow[min(x0 + 1, W - 1)], f2 = irow[min(x0 + 2, W - 1)];
+        for (int c = 0; c < tw; c++) {
+            const uint32_t f3 = irow[min(x0 + c + 3, W - 1)];
+            const uint32_t t = trow[c];
+            a[0] += t * f0;
+            a[1] += t * f1;
+            a[2] += t * f2;
+            a[3] += t * f3;
+            q[0] += f0 * f0;
+            q[1] += f1 * f1;
+            q[2] += f2 * f2;
+            q[3] += f3 * f3;
+            f0 = f1;
+            f1 = f2;
+            f2 = f3;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            acc[k] += a[k];
+            sq[k] += q[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (x0 + k < rw) {
+            num[(size_t)y * rw + x0 + k] = acc[k];
+            wsum2[(size_t)y * rw + x0 + k] = sq[k];
+        }
+}
+
+extern "C" int abub_match_ccorr_dev(const uint8_t *img, int W, int H, const uint8_t *tmpl, int tw, int th,
+                                    unsigned long long *num, unsigned long long *wsum2, void *stream)
+{
+    if (!img || !tmpl || !num || !wsum2 || W <= 0 || H <= 0 || tw <= 0 || th <= 0 || tw > W || th > H || tw > 4096)
+        return set_err(ABUB_E_INVALID, "abub_match_ccorr_dev: bad arguments");
+    const int rw = W - tw + 1, rh = H - th + 1;
+    dim3 grid((rw + 255) / 256, rh), block(64);
+    if (rh > 65535)
+        return set_err(ABUB_E_INVALID, "abub_match_ccorr_dev: image too tall");
+    hipLaunchKernelGGL(k_match_ccorr, grid, block, 0, (hipStream_t)stream, img, W, H, tmpl, tw, th, rw, rh, num, wsum2);
+    HIPCHK(hipGetLastError());
+    return ABUB_OK;
+}
+
+// img = sat(img - sub) in place + 256-bin histogram (`overTheSigma -= diff_frame`, L3Localizer.cpp:362)
+__global__ __launch_bounds__(256) void k_subsat_hist(uint8_t *__restrict__ img, const uint8_t *__restrict__ sub, size_t n,
+                                                     uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t lh[256];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        int v = (int)img[i] - (int)sub[i];
+        v = v < 0 ? 0 : v;
+        img[i] = (uint8_t)v;
+        if (v)
+            atomicAdd(&lh[v], 1u);
+    }
+    __syncthreads();
+    uint32_t c = lh[threadIdx.x];
+    if (c && threadIdx.x)
+        atomicAdd(&hist[threadIdx.x], c);
+}
+
+extern "C" int abub_subsat_hist_dev(uint8_t *img, const uint8_t *sub, int W, int H, uint32_t *hist, void *stream)
+{
+    if (!img || !sub || !hist || W <= 0 || H <= 0)
+        return set_err(ABUB_E_INVALID, "abub_subsat_hist_dev: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    size_t n = (size_t)W * H;
+    HIPCHK(hipMemsetAsync(hist, 0, 256 * sizeof(uint32_t), st));
+    int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
+    hipLaunchKernelGGL(k_subsat_hist, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, img, sub, n, hist);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_hist_bin0, dim3(1), dim3(64), 0, st, hist, (uint32_t)n);
+    HIPCHK(hipGetLastError());
+    return ABUB_OK;
+}

@@ -236,6 +236,20 @@ def blob_stats(xy):
     return dict(zip(("x", "y", "w", "h", "area", "m00", "m10", "m01"), list(out)))
 
 
+def best_match(num, wsum2, tmpl):
+    L = lib()
+    u64p = C.POINTER(C.c_uint64)
+    L.abh_best_match.argtypes = [u64p, u64p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    num = np.ascontiguousarray(num, dtype=np.uint64)
+    wsum2 = np.ascontiguousarray(wsum2, dtype=np.uint64)
+    tmpl = np.ascontiguousarray(tmpl, dtype=np.uint8)
+    rh, rw = num.shape
+    bx, by = C.c_float(), C.c_float()
+    L.abh_best_match(num.ctypes.data_as(u64p), wsum2.ctypes.data_as(u64p), rw, rh, tmpl.ctypes.data_as(_u8p),
+                     tmpl.shape[1], tmpl.shape[0], C.byref(bx), C.byref(by))
+    return bx.value, by.value
+
+
 class Significance:
     def __init__(self, tss):
         self._h = lib().abh_sig_new()
@@ -316,9 +330,13 @@ class Pipeline:
         except Exception:
             pass
 
-    def run(self, frames, mu, sigma6, stream=0):
-        """frames/mu/sigma6: device pointers (ints) or torch tensors."""
+    def run(self, frames, mu, sigma6, stream=0, sigma=None):
+        """frames/mu/sigma6 (and optionally sigma, needed only if a stack falls back to the drop-in path for the
+        bellows veto): device pointers (ints) or torch tensors."""
         p = [x.data_ptr() if hasattr(x, "data_ptr") else int(x) for x in (frames, mu, sigma6)]
+        if sigma is not None:
+            lib().abh_pipe_set_sigma.argtypes = [C.c_void_p, C.c_void_p]
+            lib().abh_pipe_set_sigma(self._h, sigma.data_ptr() if hasattr(sigma, "data_ptr") else int(sigma))
         rc = lib().abh_pipe_run(self._h, p[0], p[1], p[2], stream)
         if rc != 0:
             raise RuntimeError("pipeline: " + lib().abh_pipe_error().decode())

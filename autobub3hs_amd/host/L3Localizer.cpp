@@ -5,6 +5,7 @@
 #include "BubbleLocalizer/L3Localizer.hpp"
 
 #include <cmath>
+#include <cstring>
 #include <iostream>
 #include <map>
 #include <mutex>
@@ -42,6 +43,7 @@ L3Localizer::~L3Localizer()
 }
 
 // threshold (TOZERO tozeroThr, then BINARY|OTSU) + external contours of the context's current image
+static cv::Mat cachedMask(const std::string &path);
 static thread_local abub::ContourFinder t_finder;
 
 static void contoursOfCurrentImage(abub::EventData &ev, const uint32_t *hist, int tozeroThr,
@@ -75,9 +77,18 @@ static BubbleImageFrame describe(const std::vector<cv::Point> &contour, const cv
     return f;
 }
 
-// L3Localizer.cpp:215-460.  The bellows-template subtraction (:303-369, "next" row 3 of the scope
-// table) is not implemented: when every contour lies in the bellows mask the code takes the
-// reference's "template not loadable" branch (:297-301): contours are re-found and kept.
+static void trackResident(abub::EventData &ev, int frame, const cv::Mat &templ, cv::Point2f &best)
+{
+    if (templ.cols > ev.W || templ.rows > ev.H)
+        throw std::runtime_error("L3Localizer: bellows template larger than the frame");
+    std::vector<unsigned long long> num, w2;
+    ev.matchTerms(frame, templ, num, w2);
+    abub::bestMatchFromTerms(num.data(), w2.data(), ev.W - templ.cols + 1, ev.H - templ.rows + 1, templ, best.x, best.y);
+}
+
+// L3Localizer.cpp:215-460, including the bellows-movement veto (:292-390): when every genesis contour lies in the
+// bellows mask, the bellows template is located in the trigger and pre-trigger frames, its motion is rendered as a
+// ProcessFrame of two synthetic frames on the overlap ROI and subtracted from D before thresholding again.
 void L3Localizer::CalculateInitialBubbleParams(void)
 {
     abub::EventData &ev = device();
@@ -106,9 +117,42 @@ void L3Localizer::CalculateInitialBubbleParams(void)
                 std::cout << "Found bubble in bellows mask." << std::endl;
         }
         if (allInBellowsMask) {
-            if (!abub::g_quietAnalyzers)
-                std::cout << "Template image not loadable for event " << EventID << " camera " << CameraNumber
-                      << "; cannot veto bellows movement triggers" << std::endl;
+            const std::string path = MaskDir + "/cam" + std::to_string(CameraNumber) + "_bellows_template.png";
+            cv::Mat TemplateImage = cachedMask(path);
+            if (TemplateImage.empty()) {
+                if (!abub::g_quietAnalyzers)
+                    std::cout << "Template image not loadable for event " << EventID << " camera " << CameraNumber
+                              << "; cannot veto bellows movement triggers" << std::endl;
+            } else {
+                const int W = ev.W, H = ev.H, tw = TemplateImage.cols, th = TemplateImage.rows;
+                cv::Point2f pt, pp;
+                trackResident(ev, MatTrigFrame, TemplateImage, pt);
+                trackResident(ev, pre, TemplateImage, pp);
+                if (pt.x >= pp.x) { // nudge the two copies one pixel apart (:318-325)
+                    pt.x++;
+                    pp.x--;
+                } else {
+                    pt.x--;
+                    pp.x++;
+                }
+                const cv::Rect rt((int)pt.x, (int)pt.y, tw, th), rp((int)pp.x, (int)pp.y, tw, th);
+                auto inside = [&](const cv::Rect &r) { return r.x >= 0 && r.y >= 0 && r.x + r.width <= W && r.y + r.height <= H; };
+                if (!inside(rt) || !inside(rp))
+                    throw std::runtime_error("L3Localizer: bellows template position outside the frame");
+                cv::Mat trig_copy = cv::Mat::zeros(H, W, CV_8U), preTrig_copy = cv::Mat::zeros(H, W, CV_8U);
+                for (int r = 0; r < th; ++r) {
+                    std::memcpy(trig_copy.ptr<uchar>(rt.y + r) + rt.x, TemplateImage.ptr<uchar>(r), (size_t)tw);
+                    std::memcpy(preTrig_copy.ptr<uchar>(rp.y + r) + rp.x, TemplateImage.ptr<uchar>(r), (size_t)tw);
+                }
+                cv::Rect diffROI = GetDiffROI(pt, pp, TemplateImage);
+                if (diffROI.width < 0 || diffROI.height < 0 || !inside(diffROI))
+                    throw std::runtime_error("L3Localizer: bellows ROI outside the frame");
+                cv::Mat diff_frame;
+                ProcessFrame(trig_copy, preTrig_copy, diff_frame, 5, diffROI); // uses the frame slab: D is recomputed below
+                ev.diffFrame(MatTrigFrame, pre);
+                hist = ev.subtractFromCurrent(diff_frame); // overTheSigma -= diff_frame (:362)
+                contoursOfCurrentImage(ev, hist, loc_thres, contours);
+            }
             largestBoxArea = 0;
             minRect.clear();
             for (auto &c : contours) {
@@ -259,9 +303,21 @@ cv::Rect L3Localizer::GetDiffROI(cv::Point2f p1, cv::Point2f p2, cv::Mat &frame)
     int dx = (int)(std::min(p1.x, p2.x) + frame.cols - sx), dy = (int)(std::min(p1.y, p2.y) + frame.rows - sy);
     return cv::Rect(sx, sy, dx, dy);
 }
-void L3Localizer::TrackAFeature(cv::Mat &, cv::Mat, cv::Point2f &)
+// public form on an arbitrary host frame (L3Localizer.cpp:473-543): the frame is staged as a one-frame stack
+void L3Localizer::TrackAFeature(cv::Mat &frame, cv::Mat TemplateImage, cv::Point2f &BestMatchLoc)
 {
-    throw std::runtime_error("L3Localizer::TrackAFeature (bellows template matching) is not implemented yet (scope row 8f #3)");
+    if (frame.empty() || TemplateImage.empty() || TemplateImage.cols > frame.cols || TemplateImage.rows > frame.rows)
+        throw std::runtime_error("L3Localizer::TrackAFeature: empty image or template larger than the frame");
+    abub::DeviceContext &dc = abub::DeviceContext::forThread(frame.cols, frame.rows, 2);
+    const uint8_t *fr[1] = {frame.data};
+    abub::check(abub_ctx_upload_stack(dc.ctx, fr, 1), "abub_ctx_upload_stack");
+    dc.residentEvent = nullptr;
+    const int rw = frame.cols - TemplateImage.cols + 1, rh = frame.rows - TemplateImage.rows + 1;
+    std::vector<unsigned long long> num((size_t)rw * rh), w2((size_t)rw * rh);
+    abub::check(abub_ctx_match_template(dc.ctx, 0, TemplateImage.data, TemplateImage.cols, TemplateImage.rows, num.data(),
+                                        w2.data()),
+                "abub_ctx_match_template");
+    abub::bestMatchFromTerms(num.data(), w2.data(), rw, rh, TemplateImage, BestMatchLoc.x, BestMatchLoc.y);
 }
 void L3Localizer::CalculateInitialBubbleParamsCam2(void) {}      // dead upstream (L3Localizer.cpp:547)
 void L3Localizer::CalculatePostTriggerFrameParamsCam2(int) {}    // dead upstream

@@ -12,6 +12,7 @@
 
 #include "AlgorithmTraining/Trainer.hpp"
 #include "AnalyzerUnit.hpp"
+#include "ImageEntropyMethods/ImageEntropyMethods.hpp"
 #include "BubbleLocalizer/L3Localizer.hpp"
 #include "PICOFormatWriter/PICOFormatWriterV4.hpp"
 #include "ParseFolder/Parser.hpp"
@@ -385,6 +386,19 @@ void abh_blob_stats(const int *xy, int n, double *out /*x,y,w,h,area,m00,m10,m01
     out[5] = m.m00;
     out[6] = m.m10;
     out[7] = m.m01;
+}
+void abh_best_match(const unsigned long long *num, const unsigned long long *wsum2, int rw, int rh, const uint8_t *tmpl,
+                    int tw, int th, float *bx, float *by)
+{
+    cv::Mat t(th, tw, CV_8U);
+    std::memcpy(t.data, tmpl, (size_t)tw * th);
+    abub::bestMatchFromTerms(num, wsum2, rw, rh, t, *bx, *by);
+}
+float abh_entropy_frame(const uint8_t *img, int W, int H)
+{
+    cv::Mat m(H, W, CV_8U);
+    std::memcpy(m.data, img, (size_t)W * H);
+    return calculateEntropyFrame(m);
 }
 // significance state machine probe: feeds histograms sequentially
 void *abh_sig_new() { return new std::vector<std::vector<int>>(256); }

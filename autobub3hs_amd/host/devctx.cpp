@@ -164,6 +164,24 @@ const uint32_t *EventOnDevice::postTrig(int i, cv::Mat *out)
     return lastHist_;
 }
 
+void EventOnDevice::matchTerms(int i, const cv::Mat &templ, std::vector<unsigned long long> &num,
+                               std::vector<unsigned long long> &wsum2)
+{
+    DeviceContext &dc = resident();
+    const size_t n = (size_t)(W - templ.cols + 1) * (H - templ.rows + 1);
+    num.resize(n);
+    wsum2.resize(n);
+    check(abub_ctx_match_template(dc.ctx, i, templ.data, templ.cols, templ.rows, num.data(), wsum2.data()),
+          "abub_ctx_match_template");
+}
+
+const uint32_t *EventOnDevice::subtractFromCurrent(const cv::Mat &sub)
+{
+    DeviceContext &dc = DeviceContext::forThread(W, H, F);
+    check(abub_ctx_subtract_image(dc.ctx, sub.data, lastHist_), "abub_ctx_subtract_image");
+    return lastHist_;
+}
+
 void EventOnDevice::foreground(int thr, std::vector<uint32_t> &idx)
 {
     DeviceContext &dc = DeviceContext::forThread(W, H, F);

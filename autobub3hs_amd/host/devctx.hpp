@@ -4,6 +4,7 @@
 #define ABUB3HS_DEVCTX_HPP
 
 #include <cstdint>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -52,6 +53,16 @@ public:
     virtual const uint32_t *postTrig(int i, cv::Mat *out = nullptr) = 0;
     // foreground (v > thr) raster indices of the current image
     virtual void foreground(int thr, std::vector<uint32_t> &idx) = 0;
+    // bellows veto: exact correlation terms of frame i against a template ((H-th+1) x (W-tw+1) placements)
+    virtual void matchTerms(int i, const cv::Mat &templ, std::vector<unsigned long long> &num,
+                            std::vector<unsigned long long> &wsum2) = 0;
+    // current image = saturate(current image - sub); returns the new histogram
+    virtual const uint32_t *subtractFromCurrent(const cv::Mat &sub) = 0;
+};
+
+// thrown by a provider that cannot serve a request (the batched pipeline re-runs such a stack one at a time)
+struct NeedsDropInPath : public std::runtime_error {
+    explicit NeedsDropInPath(const char *what) : std::runtime_error(what) {}
 };
 
 // Decoded frames of one (event, camera), pushed through the per-thread context on demand.
@@ -70,6 +81,9 @@ public:
     const uint32_t *diffFrameROI(int i, int ref, cv::Rect roi, cv::Mat *out = nullptr) override;
     const uint32_t *postTrig(int i, cv::Mat *out = nullptr) override;
     void foreground(int thr, std::vector<uint32_t> &idx) override;
+    void matchTerms(int i, const cv::Mat &templ, std::vector<unsigned long long> &num,
+                    std::vector<unsigned long long> &wsum2) override;
+    const uint32_t *subtractFromCurrent(const cv::Mat &sub) override;
 
 private:
     DeviceContext &resident();

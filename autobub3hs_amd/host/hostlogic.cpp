@@ -387,6 +387,70 @@ void approxChainTC89L1(cv::Point origin, const std::vector<signed char> &codes, 
         out.push_back(a[cur].pt);
 }
 
+void bestMatchFromTerms(const unsigned long long *num, const unsigned long long *wsum2, int rw, int rh,
+                        const cv::Mat &templ, float &bx, float &by)
+{
+    const size_t n = (size_t)rw * rh;
+    // template norm the way cv::matchTemplate derives it (meanStdDev, then sqrt(sdv^2 + mean^2) / sqrt(1/N))
+    const double N = (double)templ.total();
+    double sum = 0, sq = 0;
+    for (size_t i = 0; i < templ.total(); ++i) {
+        const double v = templ.data[i];
+        sum += v;
+        sq += v * v;
+    }
+    const double invArea = 1. / N, mean = sum * invArea;
+    const double var = sq * invArea - mean * mean;
+    const double sdv = std::sqrt(var > 0 ? var : 0);
+    double templNorm = std::sqrt(sdv * sdv + mean * mean);
+    templNorm /= std::sqrt(invArea);
+    std::vector<float> res(n);
+    for (size_t i = 0; i < n; ++i) {
+        double v = (double)(float)(double)num[i]; // the correlation plane is CV_32F
+        const double w2 = (double)wsum2[i];
+        const double lim = 10 * FLT_EPSILON * w2;
+        const double t = (w2 <= std::min(0.5, lim)) ? 0 : std::sqrt(w2) * templNorm;
+        if (std::fabs(v) < t)
+            v /= t;
+        else if (std::fabs(v) < t * 1.125)
+            v = v > 0 ? 1 : -1;
+        else
+            v = 0;
+        res[i] = (float)v;
+    }
+    double smin = res[0], smax = res[0];
+    for (size_t i = 1; i < n; ++i) {
+        smin = std::min(smin, (double)res[i]);
+        smax = std::max(smax, (double)res[i]);
+    }
+    const double scale = (smax - smin > DBL_EPSILON) ? 1. / (smax - smin) : 0;
+    const float a = (float)scale, b = (float)(0.0 - smin * scale);
+    size_t best = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const float v = res[i] * a;
+        res[i] = v + b;
+        if (res[i] > res[best])
+            best = i;
+    }
+    // strict '>' above keeps the first maximum; the loop order is raster order like cv::minMaxLoc
+    const int mx = (int)(best % rw), my = (int)(best / rw);
+    float sx = 0.f, sy = 0.f, mass = 0.f;
+    for (int i = -1; i <= 1; ++i)
+        for (int j = -1; j <= 1; ++j) {
+            const int x = mx + i, y = my + j;
+            if (x < 0 || y < 0 || x >= rw || y >= rh)
+                continue; // unchecked upstream
+            const float pv = res[(size_t)y * rw + x];
+            const float px = (float)x * pv, py = (float)y * pv;
+            sx = sx + px;
+            sy = sy + py;
+            mass = mass + pv;
+        }
+    const float inv = (float)(1.0 / mass);
+    bx = sx * inv;
+    by = sy * inv;
+}
+
 cv::Rect boundingRectOf(const std::vector<cv::Point> &pts)
 {
     if (pts.empty())

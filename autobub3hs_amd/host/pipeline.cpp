@@ -87,6 +87,14 @@ public:
         throw std::runtime_error("BatchEventData: ROI diff is not available in the batched path");
     }
     const uint32_t *postTrig(int i, cv::Mat *) override { return find(1, i, 0); }
+    void matchTerms(int, const cv::Mat &, std::vector<unsigned long long> &, std::vector<unsigned long long> &) override
+    {
+        throw NeedsDropInPath("bellows veto requested in the batched path");
+    }
+    const uint32_t *subtractFromCurrent(const cv::Mat &) override
+    {
+        throw NeedsDropInPath("bellows veto requested in the batched path");
+    }
     void foreground(int thr, std::vector<uint32_t> &idx) override
     {
         if (cur < 0 || planned[cur].thr != thr)
@@ -111,6 +119,7 @@ struct StackState {
     int staged = 0;
     bool done = false;
     bool localize = false;
+    bool dropIn = false; // must be re-run through the one-at-a-time path (bellows veto)
     std::string error;
     std::vector<BubbleOut> bubbles;
     int trig = 0, status = 0, loc_thres = 3, ok = 1;
@@ -304,6 +313,8 @@ public:
     }
 
     // `callerStream`: work already queued there (e.g. the upload of the frames) is waited for first
+    const uint8_t *d_sigmaRaw = nullptr; // optional: sigma (not 6*sigma) for stacks that need the drop-in path
+
     void run(const uint8_t *d_frames, const uint8_t *d_mu, const uint8_t *d_sigma6, hipStream_t callerStream)
     {
         HIPOK(hipSetDevice(device));
@@ -333,6 +344,10 @@ public:
         std::fill(tms, tms + 8, 0.0);
         rounds = 0;
         lastPairs = 0;
+        // stacks the batched providers could not serve (bellows veto): one at a time through the drop-in path
+        for (int s = 0; s < S; ++s)
+            if (stacks[s].dropIn)
+                runDropIn(s, d_frames, d_mu);
         for (Group &G : groups) {
             if (!G.error.empty())
                 throw std::runtime_error(G.error);
@@ -345,6 +360,70 @@ public:
     }
 
 private:
+    // AnyCamAnalysis of one stack with host copies of its frames and model (the rare bellows-veto case)
+    void runDropIn(int s, const uint8_t *d_frames, const uint8_t *d_mu)
+    {
+        StackState &st_ = stacks[s];
+        st_.bubbles.clear();
+        if (!d_sigmaRaw) {
+            st_.staged = -6;
+            st_.error = "bellows veto needs the drop-in path, but no sigma image was given to the pipeline";
+            return;
+        }
+        const int e = s / C, c = s % C;
+        try {
+            std::vector<cv::Mat> frames((size_t)F);
+            for (int i = 0; i < F; ++i) {
+                frames[i].create(H, W, CV_8U);
+                HIPOK(hipMemcpy(frames[i].data, d_frames + ((size_t)s * F + i) * P, P, hipMemcpyDeviceToHost));
+            }
+            MemParser mp;
+            mp.AddFrames(std::to_string(e), c, frames, 10000);
+            Trainer t(c, {}, "", "cam%d_image%u.png", "", mp.clone(), false);
+            t.TrainedAvgImage.create(H, W, CV_8U);
+            t.TrainedSigmaImage.create(H, W, CV_8U);
+            HIPOK(hipMemcpy(t.TrainedAvgImage.data, d_mu + (size_t)c * P, P, hipMemcpyDeviceToHost));
+            HIPOK(hipMemcpy(t.TrainedSigmaImage.data, d_sigmaRaw + (size_t)c * P, P, hipMemcpyDeviceToHost));
+            t.TrainingSetSize = tss[c];
+            t.ModelId = 0; // always (re)uploaded
+            Trainer *tp = &t;
+            L3Localizer A(std::to_string(e), "", c, true, &tp, maskDir, mp.clone());
+            int staged = 0;
+            do {
+                A.FindTriggerFrame(true, A.MatTrigFrame + 1);
+                if (A.okToProceed) {
+                    A.LocalizeOMatic("");
+                    if (A.okToProceed)
+                        staged = A.BubbleList.empty() ? -1 : 0;
+                    else {
+                        staged = -8;
+                        break;
+                    }
+                } else {
+                    staged = A.TriggerFrameIdentificationStatus;
+                    break;
+                }
+            } while (A.BubbleList.size() == 0);
+            st_.staged = staged;
+            st_.trig = A.MatTrigFrame;
+            st_.status = A.TriggerFrameIdentificationStatus;
+            st_.loc_thres = A.loc_thres;
+            st_.ok = A.okToProceed;
+            for (bubble *b : A.BubbleList) {
+                BubbleOut o;
+                o.desc = b->KnownDescriptors;
+                o.dz = b->dz;
+                o.dzdt = b->dZdT();
+                o.drdt = b->dRdT();
+                st_.bubbles.push_back(std::move(o));
+            }
+        } catch (std::exception &ex) {
+            st_.error = ex.what();
+            st_.staged = -6;
+        }
+        DeviceContext::releaseThread();
+    }
+
     void runGroupNoThrow(Group &G, const uint8_t *d_frames, const uint8_t *d_mu, const uint8_t *d_sigma6)
     {
         G.error.clear();
@@ -577,6 +656,9 @@ private:
             }
             st_.staged = A->BubbleList.empty() ? -1 : 0;
             st_.done = !A->BubbleList.empty(); // no accepted bubble: search on from the next frame
+        } catch (NeedsDropInPath &) {
+            st_.dropIn = true;
+            st_.done = true;
         } catch (std::exception &e) {
             st_.error = e.what();
             st_.staged = -6;
@@ -604,6 +686,8 @@ void abh_pipe_free(void *p) { delete (abub::RunPipeline *)p; }
 
 static thread_local std::string g_pipeErr;
 const char *abh_pipe_error() { return g_pipeErr.c_str(); }
+
+void abh_pipe_set_sigma(void *p, const void *sigma_dev) { ((abub::RunPipeline *)p)->d_sigmaRaw = (const uint8_t *)sigma_dev; }
 
 int abh_pipe_run(void *p, const void *frames_dev, const void *mu_dev, const void *sigma6_dev, void *stream)
 {

@@ -44,6 +44,11 @@ private:
 // Teh-Chin (L1 curvature) dominant points of a closed Freeman chain.
 void approxChainTC89L1(cv::Point origin, const std::vector<signed char> &codes, std::vector<cv::Point> &out);
 
+// L3Localizer::TrackAFeature (L3Localizer.cpp:497-540) from the exact correlation terms the GPU returns:
+// CCORR_NORMED normalisation (double), cv::normalize to [0,1] (float32), first maximum, 3x3 centre of mass.
+void bestMatchFromTerms(const unsigned long long *num, const unsigned long long *wsum2, int rw, int rh,
+                        const cv::Mat &templ, float &bx, float &by);
+
 cv::Rect boundingRectOf(const std::vector<cv::Point> &pts);
 double contourAreaOf(const std::vector<cv::Point> &pts);
 cv::Moments momentsOf(const std::vector<cv::Point> &pts);

@@ -130,6 +130,14 @@ int abub_pairs_group_dev(const uint32_t *pairs, const uint32_t *count, uint32_t 
 int abub_fg_compact_pairs_dev(const uint8_t *img, int nimg, int W, int H, const int32_t *thr,
                               uint32_t *pairs, uint32_t cap, uint32_t *count, void *stream);
 
+/* Raw terms of cv::matchTemplate(CV_TM_CCORR_NORMED) for the bellows veto (L3Localizer::TrackAFeature,
+ * L3Localizer.cpp:499-500): for each of the (W-tw+1) x (H-th+1) placements the exact integer sums
+ * num = sum(T*I) and wsum2 = sum(I*I) over the window.  Normalisation is host work (double). */
+int abub_match_ccorr_dev(const uint8_t *img, int W, int H, const uint8_t *tmpl, int tw, int th,
+                         unsigned long long *num, unsigned long long *wsum2, void *stream);
+/* img = saturate(img - sub) in place + its 256-bin histogram (`overTheSigma -= diff_frame`, L3Localizer.cpp:362). */
+int abub_subsat_hist_dev(uint8_t *img, const uint8_t *sub, int W, int H, uint32_t *hist, void *stream);
+
 /* ------------------------------------------------------------------------------------------- */
 /* (B) context API (host buffers in/out)                                                       */
 /* ------------------------------------------------------------------------------------------- */
@@ -172,6 +180,15 @@ int abub_ctx_posttrig(abub_ctx *ctx, int i, uint8_t *O_out, uint32_t *hist_out);
 /* Foreground pixels (v > thr) of the current image as raster indices; *n = true count.
  * Returns ABUB_E_OVERFLOW if *n > cap (idx_out then holds the first cap found). */
 int abub_ctx_foreground(abub_ctx *ctx, int thr, uint32_t *idx_out, int cap, int *n);
+
+/* Bellows veto: correlation terms of resident frame i against a host template (see abub_match_ccorr_dev);
+ * num_out / wsum2_out: [(H-th+1)][(W-tw+1)] host arrays. */
+int abub_ctx_match_template(abub_ctx *ctx, int i, const uint8_t *tmpl, int tw, int th, unsigned long long *num_out,
+                            unsigned long long *wsum2_out);
+/* current image = saturate(current image - sub) with sub a host image; returns the new histogram. */
+int abub_ctx_subtract_image(abub_ctx *ctx, const uint8_t *sub, uint32_t *hist_out);
+/* Replace the current image by a host image (re-install D after a ROI ProcessFrame used the slot). */
+int abub_ctx_set_image(abub_ctx *ctx, const uint8_t *img);
 
 /* Copy the current image to the host (debug write-out / overflow fallback). */
 int abub_ctx_fetch_image(abub_ctx *ctx, uint8_t *out);

@@ -756,7 +756,17 @@ struct orc_analyzer {
     orc_bubble *bubbles;
     int nbub, capbub;
     double *sig_trace;
+    const uint8_t *bel_tmpl; /* bellows template or NULL */
+    int tW, tH;
+    int exception; /* a cv::Exception would have been thrown (ROI outside the image): status -6 */
 };
+
+void orc_analyzer_set_bellows_template(orc_analyzer *a, const uint8_t *tmpl, int tw, int th)
+{
+    a->bel_tmpl = tmpl;
+    a->tW = tw;
+    a->tH = th;
+}
 
 static void ivec_push(ivec *v, int x)
 {
@@ -986,8 +996,147 @@ static orc_bubble *new_bubble(orc_analyzer *a, const orc_blob *g)
     return b;
 }
 
-/* L3Localizer::CalculateInitialBubbleParams, L3Localizer.cpp:215-460 (bellows-template branch
- * :303-369 not restated: the oracle follows the "template not loadable" branch :297-301). */
+/* cv::matchTemplate(img, templ, result, CV_TM_CCORR_NORMED) restated from OpenCV imgproc/templmatch.cpp
+ * (crossCorr + common_matchTemplate).  The correlation itself is exact here (OpenCV evaluates it through a
+ * DFT in float32: agreement only to float rounding, parity unpinned); the normalisation follows
+ * common_matchTemplate: templNorm from meanStdDev, window energy from the double integral image,
+ * the 1.125 guard band, result stored as float32. */
+void orc_match_template_ccorr_normed(const uint8_t *img, int W, int H, const uint8_t *tmpl, int tw, int th,
+                                     float *result)
+{
+    int rw = W - tw + 1, rh = H - th + 1;
+    double N = (double)tw * th, sum = 0, sq = 0;
+    for (int i = 0; i < tw * th; i++) {
+        sum += tmpl[i];
+        sq += (double)tmpl[i] * tmpl[i];
+    }
+    double invArea = 1. / N;
+    double mean = sum * invArea;
+    double var = sq * invArea - mean * mean;
+    double sdv = sqrt(var > 0 ? var : 0);
+    double templNorm = sdv * sdv + mean * mean; /* numType == 0: templNorm = templSum2 */
+    templNorm = sqrt(templNorm);
+    templNorm /= sqrt(invArea);
+    for (int y = 0; y < rh; y++)
+        for (int x = 0; x < rw; x++) {
+            uint64_t n = 0, w2 = 0;
+            for (int r = 0; r < th; r++) {
+                const uint8_t *ir = img + (size_t)(y + r) * W + x, *tr = tmpl + (size_t)r * tw;
+                for (int c = 0; c < tw; c++) {
+                    n += (uint32_t)tr[c] * ir[c];
+                    w2 += (uint32_t)ir[c] * ir[c];
+                }
+            }
+            double num = (double)(float)(double)n; /* crossCorr result is CV_32F */
+            double wndSum2 = (double)w2, t;
+            double diff2 = wndSum2 > 0 ? wndSum2 : 0;
+            double lim = 10 * FLT_EPSILON * wndSum2;
+            if (diff2 <= (0.5 < lim ? 0.5 : lim))
+                t = 0;
+            else
+                t = sqrt(diff2) * templNorm;
+            if (fabs(num) < t)
+                num /= t;
+            else if (fabs(num) < t * 1.125)
+                num = num > 0 ? 1 : -1;
+            else
+                num = 0;
+            result[(size_t)y * rw + x] = (float)num;
+        }
+}
+
+/* L3Localizer::TrackAFeature, L3Localizer.cpp:473-543: matchTemplate, cv::normalize(0,1,NORM_MINMAX),
+ * minMaxLoc, 3x3 sub-pixel centre of mass.  Neighbours outside the result matrix (unchecked upstream)
+ * are skipped here. */
+void orc_track_feature(const uint8_t *img, int W, int H, const uint8_t *tmpl, int tw, int th, float *bx, float *by)
+{
+    int rw = W - tw + 1, rh = H - th + 1;
+    size_t n = (size_t)rw * rh;
+    float *res = (float *)malloc(sizeof(float) * n);
+    orc_match_template_ccorr_normed(img, W, H, tmpl, tw, th, res);
+    /* cv::normalize NORM_MINMAX to [0,1]: scale/shift in double, applied by convertTo in float32 */
+    double smin = res[0], smax = res[0];
+    for (size_t i = 1; i < n; i++) {
+        if (res[i] < smin) smin = res[i];
+        if (res[i] > smax) smax = res[i];
+    }
+    double scale = (1.0 - 0.0) * (smax - smin > DBL_EPSILON ? 1. / (smax - smin) : 0);
+    double shift = 0.0 - smin * scale;
+    float a = (float)scale, b = (float)shift;
+    for (size_t i = 0; i < n; i++) {
+        float v = res[i] * a;
+        res[i] = v + b;
+    }
+    /* minMaxLoc: first maximum in raster order */
+    size_t best = 0;
+    for (size_t i = 1; i < n; i++)
+        if (res[i] > res[best])
+            best = i;
+    int mx = (int)(best % rw), my = (int)(best / rw);
+    float sx = 0.f, sy = 0.f, total_mass = 0.f;
+    for (int i = -1; i <= 1; i++)
+        for (int j = -1; j <= 1; j++) {
+            int xx = mx + i, yy = my + j;
+            if (xx < 0 || yy < 0 || xx >= rw || yy >= rh)
+                continue;
+            float pv = res[(size_t)yy * rw + xx];
+            float px = (float)xx * pv, py = (float)yy * pv;
+            sx = sx + px;
+            sy = sy + py;
+            total_mass = total_mass + pv;
+        }
+    float inv_mass = (float)(1.0 / total_mass);
+    *bx = sx * inv_mass;
+    *by = sy * inv_mass;
+    free(res);
+}
+
+/* Bellows-movement subtraction, L3Localizer.cpp:303-369: locate the bellows template in the trigger and
+ * pre-trigger frames, paste it into two empty frames (nudged one pixel apart), ProcessFrame the pair on the
+ * overlap ROI and subtract the result from D.  Returns 0, or -1 where OpenCV would throw (ROI outside). */
+static int bellows_subtract(orc_analyzer *a, int trig, int pre, uint8_t *D)
+{
+    int W = a->W, H = a->H, tw = a->tW, th = a->tH;
+    size_t P = (size_t)W * H;
+    if (tw > W || th > H)
+        return -1;
+    float tx, ty, px, py;
+    orc_track_feature(frame_ptr(a, trig), W, H, a->bel_tmpl, tw, th, &tx, &ty); /* :313 */
+    orc_track_feature(frame_ptr(a, pre), W, H, a->bel_tmpl, tw, th, &px, &py);  /* :314 */
+    if (tx >= px) { /* :318-325 */
+        tx++;
+        px--;
+    } else {
+        tx--;
+        px++;
+    }
+    /* cv::Rect(float, float, int, int): implicit float -> int truncation (:345,:347) */
+    int rtx = (int)tx, rty = (int)ty, rpx = (int)px, rpy = (int)py;
+    if (rtx < 0 || rty < 0 || rtx + tw > W || rty + th > H || rpx < 0 || rpy < 0 || rpx + tw > W || rpy + th > H)
+        return -1;
+    uint8_t *tc = (uint8_t *)calloc(P, 1), *pc = (uint8_t *)calloc(P, 1), *df = (uint8_t *)malloc(P);
+    for (int r = 0; r < th; r++) {
+        memcpy(tc + (size_t)(rty + r) * W + rtx, a->bel_tmpl + (size_t)r * tw, (size_t)tw);
+        memcpy(pc + (size_t)(rpy + r) * W + rpx, a->bel_tmpl + (size_t)r * tw, (size_t)tw);
+    }
+    /* GetDiffROI, :462-470 (float expressions assigned to int) */
+    int start_x = (int)(tx > px ? tx : px), start_y = (int)(ty > py ? ty : py);
+    int delta_x = (int)((tx < px ? tx : px) + tw - start_x), delta_y = (int)((ty < py ? ty : py) + th - start_y);
+    int rc = 0;
+    if (start_x < 0 || start_y < 0 || delta_x < 0 || delta_y < 0 || start_x + delta_x > W || start_y + delta_y > H)
+        rc = -1;
+    else {
+        orc_process_frame_roi(tc, pc, a->sigma, W, H, start_x, start_y, delta_x, delta_y, df); /* :355 */
+        for (size_t i = 0; i < P; i++)
+            D[i] = sat_u8((int)D[i] - (int)df[i]); /* :362 */
+    }
+    free(tc);
+    free(pc);
+    free(df);
+    return rc;
+}
+
+/* L3Localizer::CalculateInitialBubbleParams, L3Localizer.cpp:215-460. */
 static void genesis(orc_analyzer *a, int trig, int pre)
 {
     size_t P = (size_t)a->W * a->H;
@@ -1011,7 +1160,23 @@ static void genesis(orc_analyzer *a, int trig, int pre)
             rect[nk++] = r;
         }
     }
-    if (allInBellows) { /* :292-390 with TemplateImage.empty(): contours re-found, no mask filter */
+    if (allInBellows) { /* :292-390: contours re-found, no mask filter */
+        if (a->bel_tmpl) {
+            if (bellows_subtract(a, trig, pre, D) != 0) {
+                a->exception = 1;
+                free(rect);
+                orc_contours_free(cs);
+                free(D);
+                free(mask);
+                return;
+            }
+            orc_binarize(D, a->W, a->H, a->loc_thres, mask); /* :365-367 */
+            orc_contours_free(cs);
+            cs = orc_find_contours(mask, a->W, a->H); /* :374 */
+            n = cs->n;
+            free(rect);
+            rect = (orc_blob *)calloc((size_t)(n > 0 ? n : 1), sizeof(orc_blob));
+        }
         nk = 0;
         largest = 0;
         for (int i = 0; i < n; i++) {
@@ -1097,6 +1262,8 @@ void orc_localize(orc_analyzer *a)
     if (pre < 0)
         pre = 0; /* :932-933 */
     genesis(a, t, pre); /* :942 */
+    if (a->exception)
+        return;
     if (t < 29) {       /* :944-954 */
         for (int k = 1; k <= ORC_MAX_TRACK; k++) {
             if (t + k >= a->F)
@@ -1120,6 +1287,10 @@ int orc_any_cam_analysis(orc_analyzer *a)
         orc_find_trigger(a, a->MatTrigFrame + 1);
         if (a->okToProceed) {
             orc_localize(a);
+            if (a->exception) { /* cv::Exception -> catch -> -6 (AutoBubStart3.cpp:114-117) */
+                staged = -6;
+                break;
+            }
             if (a->okToProceed)
                 staged = a->nbub > 0 ? 0 : -1; /* stageCameraOutput: -1 when list empty (V4.cpp:102) */
             else {

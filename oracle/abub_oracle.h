@@ -108,6 +108,14 @@ orc_analyzer *orc_analyzer_create(const uint8_t *frames, int F, int W, int H, co
                                   int fmH, const uint8_t *bel_mask, int bmW, int bmH);
 void orc_analyzer_destroy(orc_analyzer *a);
 
+/* Bellows template (MaskDir/cam<N>_bellows_template.png, L3Localizer.cpp:294-295); NULL = not loadable. */
+void orc_analyzer_set_bellows_template(orc_analyzer *a, const uint8_t *tmpl, int tw, int th);
+/* cv::matchTemplate(CV_TM_CCORR_NORMED) restated (imgproc/templmatch.cpp): result is (H-th+1) x (W-tw+1). */
+void orc_match_template_ccorr_normed(const uint8_t *img, int W, int H, const uint8_t *tmpl, int tw, int th,
+                                     float *result);
+/* L3Localizer::TrackAFeature, L3Localizer.cpp:473-543: best match with 3x3 sub-pixel centre of mass. */
+void orc_track_feature(const uint8_t *img, int W, int H, const uint8_t *tmpl, int tw, int th, float *bx, float *by);
+
 /* AnalyzerUnit::calculateSignificanceFrame, AnalyzerUnit.cpp:435-504 on a histogram. */
 double orc_significance(orc_analyzer *a, const uint32_t hist[256], int store);
 

@@ -92,6 +92,9 @@ def lib():
     L.orc_get_bubble_drdt.restype = C.c_float
     L.orc_get_sig_trace.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
     L.orc_get_pixcount_len.argtypes = [C.c_void_p, C.c_int]
+    L.orc_analyzer_set_bellows_template.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int]
+    L.orc_match_template_ccorr_normed.argtypes = [_u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.orc_track_feature.argtypes = [_u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.orc_format_header.argtypes = [C.c_char_p, C.c_int]
     L.orc_format_event.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_int, C.c_int,
                                    C.c_char_p, C.c_int]
@@ -208,7 +211,7 @@ class Analyzer:
     """One in-memory (event, camera) driven through the oracle's AnalyzerUnit/L3Localizer restatement."""
 
     def __init__(self, frames, mu, sigma, training_set_size, frame_ok=None, fid_mask=None,
-                 bel_mask=None):
+                 bel_mask=None, bel_template=None):
         self._keep = []
         self.frames = _img(frames)
         F, H, W = self.frames.shape
@@ -231,6 +234,10 @@ class Analyzer:
         self.F = F
         self._h = lib().orc_analyzer_create(_p(self.frames), F, W, H, _p(self.mu), _p(self.sigma),
                                             int(training_set_size), fo, fm, fw, fh, bm, bw, bh)
+        if bel_template is not None:
+            t = _img(bel_template)
+            self._keep.append(t)
+            lib().orc_analyzer_set_bellows_template(self._h, _p(t), t.shape[1], t.shape[0])
 
     def close(self):
         if self._h:
@@ -317,3 +324,21 @@ def format_event(analyzers, staged, run_number, event, frame_offset):
     w = lib().orc_format_event(hs, st, n, run_number.encode(), int(event), int(frame_offset), buf, len(buf))
     assert w >= 0
     return buf.raw[:w].decode()
+
+
+def match_template(img, tmpl):
+    img, tmpl = _img(img), _img(tmpl)
+    H, W = img.shape
+    th, tw = tmpl.shape
+    res = np.zeros((H - th + 1, W - tw + 1), np.float32)
+    lib().orc_match_template_ccorr_normed(_p(img), W, H, _p(tmpl), tw, th, res.ctypes.data_as(C.POINTER(C.c_float)))
+    return res
+
+
+def track_feature(img, tmpl):
+    img, tmpl = _img(img), _img(tmpl)
+    H, W = img.shape
+    th, tw = tmpl.shape
+    bx, by = C.c_float(), C.c_float()
+    lib().orc_track_feature(_p(img), W, H, _p(tmpl), tw, th, C.byref(bx), C.byref(by))
+    return bx.value, by.value

@@ -253,3 +253,16 @@ def test_batched_pipeline_equals_oracle(oracle, W, H):
     t = pipe.timing()
     assert t["rounds"] >= 1
     pipe.close()
+
+
+def test_image_entropy_methods_free_function(oracle):
+    import ctypes as C
+
+    L = host.lib()
+    L.abh_entropy_frame.restype = C.c_float
+    L.abh_entropy_frame.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int]
+    rs = np.random.RandomState(4)
+    for shape in [(64, 96), (33, 47)]:
+        img = ((rs.rand(*shape) < 0.2) * rs.randint(0, 256, shape)).astype(np.uint8)
+        got = L.abh_entropy_frame(img.ctypes.data_as(C.POINTER(C.c_uint8)), shape[1], shape[0])
+        assert got == oracle.entropy16(img)
