@@ -292,19 +292,21 @@ __device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, K2Ro
 {
     constexpr int NP = 2 * NDW;
     // ---- pos / neg planes as u16 pairs (AnalyzerUnit.cpp:351-352) -----------------------------
+    // sat(sat(c - r) - s) == sat(c - (r + s)) for s >= 0, and r + s <= 510 fits the u16 lane: one plain
+    // 32-bit add (VOP2) + one saturating packed subtract per plane instead of two packed subtracts
     uint32_t Xp[NP], Xn[NP];
 #pragma unroll
     for (int d = 0; d < NDW; d++) {
         uint32_t c0 = widen_lo(in.c[d]), c1 = widen_hi(in.c[d]);
         uint32_t r0 = widen_lo(in.r[d]), r1 = widen_hi(in.r[d]);
         uint32_t s0 = widen_lo(in.s[d]), s1 = widen_hi(in.s[d]);
-        Xp[2 * d] = pk_subsat(pk_subsat(c0, r0), s0);
-        Xn[2 * d] = pk_subsat(pk_subsat(r0, c0), s0);
-        Xp[2 * d + 1] = pk_subsat(pk_subsat(c1, r1), s1);
-        Xn[2 * d + 1] = pk_subsat(pk_subsat(r1, c1), s1);
+        Xp[2 * d] = pk_subsat(c0, r0 + s0);
+        Xn[2 * d] = pk_subsat(r0, c0 + s0);
+        Xp[2 * d + 1] = pk_subsat(c1, r1 + s1);
+        Xn[2 * d + 1] = pk_subsat(r1, c1 + s1);
     }
 
-    // ---- horizontal 1-4-6-4-1 (+8 rounding share per row; AnalyzerUnit.cpp:359-360) -----------
+    // ---- horizontal 1-4-6-4-1 (AnalyzerUnit.cpp:359-360; the +128 rounding is applied at the end) ----
     // left pair (p[-2],p[-1]) and right pair (p[n],p[n+1]): neighbour lanes, reflect-101 at the edges
     uint32_t reflLp = __builtin_amdgcn_perm(Xp[0], Xp[1], 0x07060100u); // (X1.lo, X0.hi) = (p2,p1)
     uint32_t reflLn = __builtin_amdgcn_perm(Xn[0], Xn[1], 0x07060100u);
@@ -331,8 +333,8 @@ __device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, K2Ro
             uint32_t ap1p = __builtin_amdgcn_alignbit(xp1p, Xp[j], 16); // (p[2j+1], p[2j+2])
             uint32_t ap1n = __builtin_amdgcn_alignbit(xp1n, Xn[j], 16);
             uint32_t sp = am1p + ap1p, sn = am1n + ap1n;
-            uint32_t tp = xm1p + xp1p + 0x00080008u, tn = xm1n + xp1n + 0x00080008u;
-            Hp[j] = pk_madk<6>(Xp[j], (sp << 2) + tp); // every u16 lane <= 4088
+            uint32_t tp = xm1p + xp1p, tn = xm1n + xp1n;
+            Hp[j] = pk_madk<6>(Xp[j], (sp << 2) + tp); // every u16 lane <= 4080
             Hn[j] = pk_madk<6>(Xn[j], (sn << 2) + tn);
             am1p = ap1p;
             am1n = ap1n;
@@ -341,23 +343,24 @@ __device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, K2Ro
 
     // ---- vertical 1-4-6-4-1, (S+128)>>8, absdiff (AnalyzerUnit.cpp:370) -----------------------
     uint32_t Vp[NP], Vn[NP];
-    uint32_t big = 0; // OR of all sums: if no u16 lane reaches 256 every rounded value, hence D, is 0
+    uint32_t big = 0; // OR of all sums S: if no u16 lane reaches 128 every (S+128)>>8, hence D, is 0
 #pragma unroll
     for (int j = 0; j < NP; j++) {
         Vp[j] = A.pa0[j] + Hp[j];
         Vn[j] = A.na0[j] + Hn[j];
-        A.pa0[j] = lshl2_add(Hp[j], A.pa1[j]);
-        A.na0[j] = lshl2_add(Hn[j], A.na1[j]);
+        const uint32_t p4 = Hp[j] << 2, n4 = Hn[j] << 2; // shared by a0 and a2 (plain VOP2 shift + adds)
+        A.pa0[j] = A.pa1[j] + p4;
+        A.na0[j] = A.na1[j] + n4;
         A.pa1[j] = pk_madk<6>(Hp[j], A.pa2[j]);
         A.na1[j] = pk_madk<6>(Hn[j], A.na2[j]);
-        A.pa2[j] = lshl2_add(Hp[j], Hprev.hp[j]);
-        A.na2[j] = lshl2_add(Hn[j], Hprev.hn[j]);
+        A.pa2[j] = Hprev.hp[j] + p4;
+        A.na2[j] = Hprev.hn[j] + n4;
         big |= Vp[j] | Vn[j];
     }
     uint32_t Dp[NP];
     uint32_t any = 0;
-    // wave-uniform shortcut: for almost every row of almost every frame all sums stay below 256
-    const bool quiet = __builtin_amdgcn_ballot_w64((big & 0xff00ff00u) != 0) == 0;
+    // wave-uniform shortcut: for almost every row of almost every frame all sums stay below 128
+    const bool quiet = __builtin_amdgcn_ballot_w64((big & 0xff80ff80u) != 0) == 0;
     if (quiet) {
 #pragma unroll
         for (int j = 0; j < NP; j++)
@@ -365,8 +368,9 @@ __device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, K2Ro
     } else {
 #pragma unroll
         for (int j = 0; j < NP; j++) {
-            uint32_t rp = __builtin_amdgcn_perm(0u, Vp[j], 0x0c030c01u); // byte1, byte3 of the u16 lanes
-            uint32_t rn = __builtin_amdgcn_perm(0u, Vn[j], 0x0c030c01u);
+            // (S+128)>>8: byte1 / byte3 of the u16 lanes after the rounding add (S <= 65280: no lane overflow)
+            uint32_t rp = __builtin_amdgcn_perm(0u, Vp[j] + 0x00800080u, 0x0c030c01u);
+            uint32_t rn = __builtin_amdgcn_perm(0u, Vn[j] + 0x00800080u, 0x0c030c01u);
             Dp[j] = pk_absdiff(rp, rn);
             any |= Dp[j];
         }
