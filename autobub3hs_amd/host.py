@@ -341,6 +341,15 @@ class Pipeline:
         if rc != 0:
             raise RuntimeError("pipeline: " + lib().abh_pipe_error().decode())
 
+    def run_host(self, frames_host, mu, sigma6):
+        """Streamed mode: `frames_host` is a HOST tensor / pointer ([E][C][F][H][W], pinned for full PCIe rate);
+        stack groups are uploaded and processed in a pipeline."""
+        L = lib()
+        L.abh_pipe_run_host.argtypes = [C.c_void_p] * 4
+        p = [x.data_ptr() if hasattr(x, "data_ptr") else int(x) for x in (frames_host, mu, sigma6)]
+        if L.abh_pipe_run_host(self._h, p[0], p[1], p[2]) != 0:
+            raise RuntimeError("pipeline: " + L.abh_pipe_error().decode())
+
     def timing(self):
         out = (C.c_double * 9)()
         rounds = lib().abh_pipe_timing(self._h, out)

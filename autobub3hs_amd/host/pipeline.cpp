@@ -304,6 +304,10 @@ public:
         }
         if (stage1Stream)
             (void)hipStreamDestroy(stage1Stream);
+        if (copyStream)
+            (void)hipStreamDestroy(copyStream);
+        for (auto &e : copied)
+            (void)hipEventDestroy(e);
         for (void *p : devAllocs)
             (void)hipFree(p);
         for (void *p : hostAllocs)
@@ -314,11 +318,41 @@ public:
 
     // `callerStream`: work already queued there (e.g. the upload of the frames) is waited for first
     const uint8_t *d_sigmaRaw = nullptr; // optional: sigma (not 6*sigma) for stacks that need the drop-in path
+    uint8_t *d_ownFrames = nullptr;      // frame slab owned by the pipeline (streamed mode only)
+    hipStream_t copyStream = nullptr;
+    std::vector<hipEvent_t> copied;
+
+    // Streamed mode (BASELINE configs[4]): the run sits in HOST memory (ideally pinned).  Stack groups are
+    // uploaded in order on a copy stream; the trigger search of group g waits only for its own upload, so it
+    // overlaps the transfer of group g+1 (double buffering in time; the slab itself stays resident for the
+    // localisation stages).
+    void runFromHost(const uint8_t *h_frames, const uint8_t *d_mu, const uint8_t *d_sigma6)
+    {
+        HIPOK(hipSetDevice(device));
+        if (!d_ownFrames) {
+            d_ownFrames = dalloc<uint8_t>((size_t)S * F * P);
+            HIPOK(hipStreamCreateWithFlags(&copyStream, hipStreamNonBlocking));
+            copied.resize(ngroups);
+            for (auto &e : copied)
+                HIPOK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        for (int g = 0; g < ngroups; ++g) {
+            const Group &G = groups[g];
+            const size_t off = (size_t)G.s0 * F * P, n = (size_t)(G.s1 - G.s0) * F * P;
+            HIPOK(hipMemcpyAsync(d_ownFrames + off, h_frames + off, n, hipMemcpyHostToDevice, copyStream));
+            HIPOK(hipEventRecord(copied[g], copyStream));
+        }
+        waitCopies = true;
+        run(d_ownFrames, d_mu, d_sigma6, nullptr);
+        waitCopies = false;
+    }
+    bool waitCopies = false;
 
     void run(const uint8_t *d_frames, const uint8_t *d_mu, const uint8_t *d_sigma6, hipStream_t callerStream)
     {
         HIPOK(hipSetDevice(device));
-        HIPOK(hipStreamSynchronize(callerStream));
+        if (!waitCopies)
+            HIPOK(hipStreamSynchronize(callerStream));
         g_quietAnalyzers = true;
         double t0 = nowMs();
         stacks.clear();
@@ -326,7 +360,10 @@ public:
         // Stage 1 of every group goes to ONE stream in group order: the trigger search of group g+1 runs
         // on the GPU while the host threads of group g are in their state machines (two kernels launched on
         // different streams would simply share the chip and finish together, leaving nothing to overlap).
-        for (Group &G : groups) {
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            Group &G = groups[gi];
+            if (waitCopies)
+                HIPOK(hipStreamWaitEvent(stage1Stream, copied[gi], 0));
             const int n1 = (G.s1 - G.s0) * (F - 1);
             if (n1 > 0) {
                 check(abub_diff_hist_dev(d_frames, d_sigma6, G.d_jobs1, n1, W, H, G.d_hist1, nullptr, 0, stage1Stream),
@@ -694,6 +731,17 @@ int abh_pipe_run(void *p, const void *frames_dev, const void *mu_dev, const void
     try {
         ((abub::RunPipeline *)p)->run((const uint8_t *)frames_dev, (const uint8_t *)mu_dev, (const uint8_t *)sigma6_dev,
                                       (hipStream_t)stream);
+        return 0;
+    } catch (std::exception &e) {
+        g_pipeErr = e.what();
+        return -1;
+    }
+}
+
+int abh_pipe_run_host(void *p, const void *frames_host, const void *mu_dev, const void *sigma6_dev)
+{
+    try {
+        ((abub::RunPipeline *)p)->runFromHost((const uint8_t *)frames_host, (const uint8_t *)mu_dev, (const uint8_t *)sigma6_dev);
         return 0;
     } catch (std::exception &e) {
         g_pipeErr = e.what();

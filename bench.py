@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--threads", type=int, default=16, help="host threads of the per-event state machines")
+    ap.add_argument("--stream-steps", type=int, default=2,
+                    help="extra steps with the run uploaded from pinned host memory (PCIe-inclusive rate; 0 = skip)")
     return ap.parse_args()
 
 
@@ -123,6 +125,22 @@ def main():
     n_trig = sum(1 for r in fingerprint if r[0] == 0)
     n_bub = sum(r[2] for r in fingerprint)
 
+    # ---- PCIe-inclusive rate (reported in config only, never `value`): the same run streamed from pinned host memory
+    pcie = None
+    if args.stream_steps > 0 and rank == 0 and world == 1:
+        h_slab = torch.empty(slab.shape, dtype=torch.uint8).pin_memory()
+        h_slab.copy_(slab)
+        torch.cuda.synchronize()
+        pipe.run_host(h_slab, mu_d, s6_d)  # warm-up (allocates the pipeline-owned slab)
+        assert pipe.summary() == fingerprint, "streamed run differs from the resident run"
+        ts = time.perf_counter()
+        for _ in range(args.stream_steps):
+            pipe.run_host(h_slab, mu_d, s6_d)
+        tstream = (time.perf_counter() - ts) / args.stream_steps
+        pcie = {"frames_per_s": S * F / tstream, "ms_per_run": tstream * 1e3,
+                "GBps_host_to_hbm": S * F * P / tstream / 1e9}
+        del h_slab
+
     # ---- dominant kernel alone, HIP events on the launch stream (roofline object) ---------------
     jobs = hip.stack_jobs(S, F, 1, F - 1, 2, C, dev)
     hist = torch.empty((njobs, 256), dtype=torch.int32, device=dev)
@@ -176,6 +194,7 @@ def main():
             "triggered_stacks": n_trig, "bubbles": n_bub,
             "stage_ms": {k: round(v / args.steps, 3) for k, v in stage.items()},
             "gen_seconds": round(gen_s, 1),
+            "pcie_inclusive": pcie,
         },
         "roofline": {
             "kernel": "k2_rows<5,false,1> (fused ProcessFrame + 256-bin histogram, trigger-only mode: 3*W*H B/job)",

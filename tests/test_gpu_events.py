@@ -266,3 +266,35 @@ def test_image_entropy_methods_free_function(oracle):
         img = ((rs.rand(*shape) < 0.2) * rs.randint(0, 256, shape)).astype(np.uint8)
         got = L.abh_entropy_frame(img.ctypes.data_as(C.POINTER(C.c_uint8)), shape[1], shape[0])
         assert got == oracle.entropy16(img)
+
+
+def test_streamed_pipeline_equals_resident(oracle):
+    """BASELINE configs[4] path: the run starts in pinned host memory and is uploaded group by group while earlier
+    groups are processed; results must equal the HBM-resident run."""
+    from autobub3hs_amd import hip
+
+    dev = "cuda:0"
+    W, H, F, E, C = 1280, 96, 41, 8, 2
+    slab = np.zeros((E, C, F, H, W), np.uint8)
+    for e in range(E):
+        for c in range(C):
+            spec = synth.random_spec(W, H, F, 800 + e, c, p_second=0.3, p_none=0.2, margin=25)
+            slab[e, c] = synth.render_event(W, H, spec, 800 + e, c)
+    models = [oracle.welford(synth.training_pairs(W, H, 8, c, F)) for c in range(C)]
+    d_mu = torch.from_numpy(np.stack([m[0] for m in models])).to(dev)
+    d_s6 = hip.sigma6(torch.from_numpy(np.stack([m[1] for m in models])).to(dev))
+    h_slab = torch.from_numpy(slab).pin_memory()
+    os.environ["ABUB_PIPE_GROUPS"] = "4"
+    try:
+        pipe = host.Pipeline(0, W, H, F, E, C, [16, 16], nthreads=4)
+    finally:
+        del os.environ["ABUB_PIPE_GROUPS"]
+    pipe.run_host(h_slab, d_mu, d_s6)
+    streamed = [pipe.result(s)[:3] for s in range(E * C)]
+    pipe.run(h_slab.to(dev), d_mu, d_s6, torch.cuda.current_stream().cuda_stream)
+    resident = [pipe.result(s)[:3] for s in range(E * C)]
+    assert repr(streamed) == repr(resident)
+    for s in (0, 5, 11):
+        ref = oracle_event(oracle, slab[s // C, s % C], models[s % C][0], models[s % C][1], 16)
+        assert (streamed[s][0], streamed[s][1]) == (ref[0], ref[1])
+    pipe.close()
