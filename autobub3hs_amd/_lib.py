@@ -43,6 +43,7 @@ SIGNATURES = {
     "abub_diff_hist_compact_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp]),
     "abub_posttrig_compact_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp]),
     "abub_pairs_group_dev": (_i, [_vp, _vp, C.c_uint32, _i, _vp, _vp, _vp, _vp, _vp]),
+    "abub_pairs_group_hist_dev": (_i, [_vp, _vp, C.c_uint32, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "abub_fg_compact_pairs_dev": (_i, [_vp, _i, _i, _i, _vp, _vp, C.c_uint32, _vp, _vp]),
     "abub_match_ccorr_dev": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "abub_subsat_hist_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp]),

@@ -1375,32 +1375,101 @@ __global__ __launch_bounds__(256) void k_pairs_scatter(const uint32_t *__restric
     uint32_t n = *count;
     if (n > cap)
         n = cap;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        uint32_t w0 = pairs[2 * (size_t)i], w1 = pairs[2 * (size_t)i + 1];
-        uint32_t s = w0 & 0x00ffffffu;
-        if (s < nslots) {
-            uint32_t pos = atomicAdd(&cursor[s], 1u);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    // whole waves iterate together (the loop bound is rounded up per wave) so that the wave-uniform fast
+    // path below is legal: entries of one producer wave-row are contiguous and share their slot
+    const uint32_t nround = (n + 63u) & ~63u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += stride) {
+        const bool live = i < n;
+        uint32_t w0 = 0, w1 = 0, s = 0xffffffffu;
+        if (live) {
+            w0 = pairs[2 * (size_t)i];
+            w1 = pairs[2 * (size_t)i + 1];
+            s = w0 & 0x00ffffffu;
+            if (s >= nslots)
+                s = 0xffffffffu;
+        }
+        const uint32_t s0 = __builtin_amdgcn_readfirstlane(s);
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(s == s0);
+        uint32_t pos;
+        if (same == ~0ull) { // all 64 lanes: one atomic for the wave
+            uint32_t base = 0;
+            if (s0 != 0xffffffffu) {
+                if ((threadIdx.x & 63) == 0)
+                    base = atomicAdd(&cursor[s0], 64u);
+                base = __builtin_amdgcn_readfirstlane(base);
+            }
+            pos = base + (threadIdx.x & 63);
+        } else {
+            pos = s != 0xffffffffu ? atomicAdd(&cursor[s], 1u) : 0;
+        }
+        if (s != 0xffffffffu) {
             idx_out[pos] = w1;
             val_out[pos] = (uint8_t)(w0 >> 24);
         }
     }
 }
 
-extern "C" int abub_pairs_group_dev(const uint32_t *pairs, const uint32_t *count, uint32_t cap, int nslots,
-                                    uint32_t *scratch /* [2*nslots] */, uint32_t *offsets /* [nslots+1] */,
-                                    uint32_t *idx_out /* [cap] */, uint8_t *val_out /* [cap] */, void *stream)
+// counts per slot straight from the histograms the producing kernels already made: the number of
+// list entries of slot s is the number of its pixels with value > cthr[s]
+__global__ __launch_bounds__(64) void k_slot_counts_from_hist(const uint32_t *__restrict__ hist,
+                                                              const int32_t *__restrict__ cthr, uint32_t nslots,
+                                                              uint32_t *__restrict__ slotcount)
+{
+    const uint32_t sl = blockIdx.x;
+    if (sl >= nslots)
+        return;
+    const uint32_t *h = hist + (size_t)sl * 256;
+    const int t = cthr[sl];
+    const int l = threadIdx.x;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int b = l + 64 * k;
+        if (b > t)
+            c += h[b];
+    }
+    for (int o = 32; o > 0; o >>= 1)
+        c += __shfl_xor(c, o);
+    if (l == 0)
+        slotcount[sl] = c;
+}
+
+static int pairs_group_impl(const uint32_t *pairs, const uint32_t *count, uint32_t cap, int nslots,
+                            uint32_t *scratch, uint32_t *offsets, uint32_t *idx_out, uint8_t *val_out,
+                            const uint32_t *hist, const int32_t *cthr, void *stream)
 {
     if (!pairs || !count || !scratch || !offsets || !idx_out || !val_out || nslots <= 0 || cap == 0)
         return set_err(ABUB_E_INVALID, "abub_pairs_group_dev: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     uint32_t *slotcount = scratch, *cursor = scratch + nslots;
-    HIPCHK(hipMemsetAsync(slotcount, 0, (size_t)nslots * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(k_pairs_count, dim3(512), dim3(256), 0, st, pairs, count, cap, (uint32_t)nslots, slotcount);
+    if (hist && cthr) {
+        hipLaunchKernelGGL(k_slot_counts_from_hist, dim3(nslots), dim3(64), 0, st, hist, cthr, (uint32_t)nslots, slotcount);
+    } else {
+        HIPCHK(hipMemsetAsync(slotcount, 0, (size_t)nslots * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_pairs_count, dim3(512), dim3(256), 0, st, pairs, count, cap, (uint32_t)nslots, slotcount);
+    }
     hipLaunchKernelGGL(k_pairs_scan, dim3(1), dim3(1024), 0, st, slotcount, (uint32_t)nslots, offsets, cursor);
     hipLaunchKernelGGL(k_pairs_scatter, dim3(512), dim3(256), 0, st, pairs, count, cap, (uint32_t)nslots, cursor,
                        idx_out, val_out);
     HIPCHK(hipGetLastError());
     return ABUB_OK;
+}
+
+extern "C" int abub_pairs_group_dev(const uint32_t *pairs, const uint32_t *count, uint32_t cap, int nslots,
+                                    uint32_t *scratch /* [2*nslots] */, uint32_t *offsets /* [nslots+1] */,
+                                    uint32_t *idx_out /* [cap] */, uint8_t *val_out /* [cap] */, void *stream)
+{
+    return pairs_group_impl(pairs, count, cap, nslots, scratch, offsets, idx_out, val_out, nullptr, nullptr, stream);
+}
+
+extern "C" int abub_pairs_group_hist_dev(const uint32_t *pairs, const uint32_t *count, uint32_t cap, int nslots,
+                                         uint32_t *scratch, uint32_t *offsets, uint32_t *idx_out, uint8_t *val_out,
+                                         const uint32_t *hist, const int32_t *cthr, void *stream)
+{
+    if (!hist || !cthr)
+        return set_err(ABUB_E_INVALID, "abub_pairs_group_hist_dev: bad arguments");
+    return pairs_group_impl(pairs, count, cap, nslots, scratch, offsets, idx_out, val_out, hist, cthr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

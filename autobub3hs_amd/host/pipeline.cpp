@@ -12,6 +12,10 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -125,29 +129,106 @@ struct StackState {
     int trig = 0, status = 0, loc_thres = 3, ok = 1;
 };
 
-template <typename Fn>
-void parallelFor(int n, int nthreads, Fn fn)
-{
-    if (nthreads <= 1 || n <= 1) {
-        for (int i = 0; i < n; ++i)
-            fn(i);
-        return;
+// Persistent worker pool shared by all stack groups: a group that is waiting for the GPU lends its
+// threads to the groups that are in their host stages (no per-call thread creation either).
+class WorkerPool {
+public:
+    explicit WorkerPool(int nthreads)
+    {
+        for (int t = 0; t < nthreads; ++t)
+            workers.emplace_back([this]() { workerLoop(); });
     }
-    std::atomic<int> next{0};
-    std::vector<std::thread> th;
-    int nt = std::min(nthreads, n);
-    for (int t = 0; t < nt; ++t)
-        th.emplace_back([&]() {
-            for (;;) {
-                int i = next.fetch_add(1);
-                if (i >= n)
-                    break;
+    ~WorkerPool()
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto &t : workers)
+            t.join();
+    }
+    // runs fn(0..n-1); the caller takes part, returns when every index is done
+    void parallelFor(int n, const std::function<void(int)> &fn)
+    {
+        if (n <= 0)
+            return;
+        if (n == 1 || workers.empty()) {
+            for (int i = 0; i < n; ++i)
                 fn(i);
+            return;
+        }
+        auto batch = std::make_shared<Batch>();
+        batch->n = n;
+        batch->fn = &fn;
+        batch->remaining = n;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            batches.push_back(batch);
+        }
+        cv.notify_all();
+        runBatch(*batch); // help
+        std::unique_lock<std::mutex> lock(mu);
+        batch->done.wait(lock, [&] { return batch->remaining == 0; });
+        for (auto it = batches.begin(); it != batches.end(); ++it)
+            if (it->get() == batch.get()) {
+                batches.erase(it);
+                break;
             }
-        });
-    for (auto &t : th)
-        t.join();
-}
+    }
+
+private:
+    struct Batch {
+        int n = 0;
+        const std::function<void(int)> *fn = nullptr;
+        std::atomic<int> next{0};
+        int remaining = 0; // guarded by mu
+        std::condition_variable done;
+    };
+    void runBatch(Batch &b)
+    {
+        int finished = 0;
+        for (;;) {
+            const int i = b.next.fetch_add(1);
+            if (i >= b.n)
+                break;
+            (*b.fn)(i);
+            ++finished;
+        }
+        if (finished) {
+            std::lock_guard<std::mutex> lock(mu);
+            b.remaining -= finished;
+            if (b.remaining == 0)
+                b.done.notify_all();
+        }
+    }
+    void workerLoop()
+    {
+        std::unique_lock<std::mutex> lock(mu);
+        for (;;) {
+            std::shared_ptr<Batch> pick;
+            for (auto &b : batches)
+                if (b->next.load() < b->n) {
+                    pick = b;
+                    break;
+                }
+            if (pick) {
+                lock.unlock();
+                runBatch(*pick);
+                lock.lock();
+                continue;
+            }
+            if (stop)
+                return;
+            cv.wait(lock);
+        }
+    }
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::shared_ptr<Batch>> batches;
+    std::vector<std::thread> workers;
+    bool stop = false;
+};
 
 double nowMs()
 {
@@ -189,6 +270,7 @@ public:
     std::vector<int> tss;
     std::string maskDir;
     std::vector<Group> groups;
+    std::unique_ptr<WorkerPool> pool;
     hipStream_t stage1Stream = nullptr; // all trigger-search launches, in group order (see run())
     std::vector<void *> devAllocs, hostAllocs;
     std::vector<StackState> stacks;
@@ -233,6 +315,7 @@ public:
             ngroups = S;
         const int K = NumFramesBubbleTrack + 1;
         groups.resize(ngroups);
+        pool.reset(new WorkerPool(std::max(0, nthreads - ngroups))); // the group driver threads take part too
         // stage-1 jobs: FindTriggerFrame's pairing, ref = max(i - off, 0) with off = 1 when the model was
         // trained on fewer than 6 frames (AnalyzerUnit.cpp:185-188); `out` is relative to the group's slab
         for (int g = 0; g < ngroups; ++g) {
@@ -480,7 +563,7 @@ private:
         double t0 = nowMs();
         // ---- stage 1 (already queued by run()) -----------------------------------------------------
         // analyzers are (re)built while the GPU works
-        parallelFor(ns, G.nthreads, [&](int k) {
+        pool->parallelFor(ns, [&](int k) {
             const int s = G.s0 + k;
             StackState &st_ = stacks[s];
             const int e = s / C, c = s % C;
@@ -503,7 +586,7 @@ private:
             ++G.rounds;
             // ---- stage 2: trigger search + plan ------------------------------------------------
             double t2 = nowMs();
-            parallelFor((int)pending.size(), G.nthreads, [&](int k) { triggerAndPlan(stacks[pending[k]]); });
+            pool->parallelFor((int)pending.size(), [&](int k) { triggerAndPlan(stacks[pending[k]]); });
             G.tms[1] += nowMs() - t2;
             // ---- stage 3: batched images, thresholds, foreground ---------------------------------
             double t3 = nowMs();
@@ -516,7 +599,7 @@ private:
             G.tms[2] += nowMs() - t3;
             // ---- stage 4: localize + track -------------------------------------------------------
             double t4 = nowMs();
-            parallelFor((int)loc.size(), G.nthreads, [&](int k) { localize(stacks[loc[k]]); });
+            pool->parallelFor((int)loc.size(), [&](int k) { localize(stacks[loc[k]]); });
             G.tms[3] += nowMs() - t4;
             std::vector<int> next;
             for (int s : pending)
@@ -525,7 +608,7 @@ private:
             pending.swap(next);
         }
         // results out, analyzers released
-        parallelFor(ns, G.nthreads, [&](int k) {
+        pool->parallelFor(ns, [&](int k) {
             StackState &st_ = stacks[G.s0 + k];
             AnalyzerUnit *A = st_.analyzer.get();
             st_.trig = A->MatTrigFrame;
@@ -651,8 +734,9 @@ private:
                   "stage3 K4");
         }
         // group the list by image on the device; the host gets contiguous runs and never re-buckets
-        check(abub_pairs_group_dev(G.d_pairs, G.d_count, G.pairCap, nimg, G.d_gscratch, G.d_goff, G.d_gidx, G.d_gval,
-                                   stream),
+        // (per-slot counts come from the histograms the same launches produced: no counting pass)
+        check(abub_pairs_group_hist_dev(G.d_pairs, G.d_count, G.pairCap, nimg, G.d_gscratch, G.d_goff, G.d_gidx, G.d_gval,
+                                        G.d_hist3, G.d_thr, stream),
               "stage3 group");
         HIPOK(hipMemcpyAsync(G.h_hist3, G.d_hist3, (size_t)nimg * 1024, hipMemcpyDeviceToHost, stream));
         HIPOK(hipMemcpyAsync(G.h_count, G.d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -669,7 +753,7 @@ private:
             HIPOK(hipMemcpyAsync(G.h_gval, G.d_gval, (size_t)cnt, hipMemcpyDeviceToHost, stream));
         }
         // thresholds (TOZERO + Otsu) on the host from the histograms, while the list travels
-        parallelFor(nimg, G.nthreads, [&](int k) {
+        pool->parallelFor(nimg, [&](int k) {
             PlannedImage *p = bySlot[k];
             p->thr = binarizeThresholdFromHist(G.h_hist3 + (size_t)k * 256, P, p->tozero);
             p->fg = G.h_gidx + G.h_goff[k];

@@ -125,6 +125,13 @@ int abub_pairs_group_dev(const uint32_t *pairs, const uint32_t *count, uint32_t 
                          uint32_t *scratch /* [2*nslots] */, uint32_t *offsets /* [nslots+1] */,
                          uint32_t *idx_out /* [cap] */, uint8_t *val_out /* [cap] */, void *stream);
 
+/* Same, with the per-slot counts taken from the producers' histograms (entries of slot s = pixels of hist[s]
+ * with value > cthr[s]) instead of a counting pass over the list; valid when the list did not overflow. */
+int abub_pairs_group_hist_dev(const uint32_t *pairs, const uint32_t *count, uint32_t cap, int nslots,
+                              uint32_t *scratch, uint32_t *offsets, uint32_t *idx_out, uint8_t *val_out,
+                              const uint32_t *hist /* [nslots][256] */, const int32_t *cthr /* [nslots] */,
+                              void *stream);
+
 /* K4, batched form: one shared output list for all nimg images, pairs[2*k] = image | value << 24,
  * pairs[2*k+1] = y*W+x (unordered); *count = true total (may exceed cap). */
 int abub_fg_compact_pairs_dev(const uint8_t *img, int nimg, int W, int H, const int32_t *thr,
