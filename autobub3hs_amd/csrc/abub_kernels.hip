@@ -656,15 +656,14 @@ static int diff_hist_impl(const uint8_t *frames, const uint8_t *sigma6, const ab
         int R = rows_per_chunk;
         if (R == 0) {
             // many jobs: 8 chunks per frame (<= ~3% vertical halo re-reads, chunk id == XCD id);
-            // few jobs: short chunks so that a single frame still spreads over the chip
-            if (njobs >= 64)
-                R = (H + 7) / 8;
-            else if (njobs >= 8)
-                R = (H + 31) / 32;
-            else
+            // fewer jobs: more, shorter chunks so that the launch still offers >= ~8k waves to the chip
+            int nch = 8;
+            if ((long long)njobs * nch < 8192)
+                nch = (8192 + njobs - 1) / njobs;
+            nch = (nch + 7) / 8 * 8; // keep chunk id == XCD id
+            R = (H + nch - 1) / nch;
+            if (R < 16)
                 R = 16;
-            if (R < 8)
-                R = 8;
         }
         int nchunks = (H + R - 1) / R;
         switch (ndw) {
@@ -1153,9 +1152,13 @@ static int posttrig_impl(const uint8_t *frames, const uint8_t *mu, const uint8_t
     HIPCHK(hipMemsetAsync(hist, 0, (size_t)njobs * 256 * sizeof(uint32_t), st));
     int ndw = pick_ndw(W);
     if (ndw) {
-        int R = njobs >= 64 ? (H + 7) / 8 : (njobs >= 8 ? (H + 31) / 32 : 16);
-        if (R < 8)
-            R = 8;
+        int nch = 8;
+        if ((long long)njobs * nch < 8192)
+            nch = (8192 + njobs - 1) / njobs;
+        nch = (nch + 7) / 8 * 8;
+        int R = (H + nch - 1) / nch;
+        if (R < 16)
+            R = 16;
         int nchunks = (H + R - 1) / R;
         switch (ndw) {
         case 1: launch_k3_rows<1>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;

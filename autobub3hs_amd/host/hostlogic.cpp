@@ -189,23 +189,31 @@ void ContourFinder::find(std::vector<uint32_t> &idx, int W, int H,
         h_ = H;
         plane_.assign((size_t)(W + 2) * (H + 2), 0);
     }
-    std::sort(idx.begin(), idx.end());
+    // No sort: the raster scan only needs, per image row, the x-span that contains foreground.  One pass
+    // marks the pixels and records [min x, max x] per touched row; rows are then visited in increasing y.
     const int step = W + 2;
     signed char *img = plane_.data();
-    for (uint32_t i : idx)
-        img[(size_t)(i / W + 1) * step + (i % W + 1)] = 1;
+    int yMin = H, yMax = -1;
+    for (uint32_t i : idx) {
+        const int y = (int)(i / W);
+        yMin = std::min(yMin, y);
+        yMax = std::max(yMax, y);
+    }
+    rowLo_.assign((size_t)(yMax - yMin + 1), W);
+    rowHi_.assign((size_t)(yMax - yMin + 1), -1);
+    for (uint32_t i : idx) {
+        const int y = (int)(i / W), x = (int)(i % W);
+        img[(size_t)(y + 1) * step + (x + 1)] = 1;
+        rowLo_[y - yMin] = std::min(rowLo_[y - yMin], x);
+        rowHi_[y - yMin] = std::max(rowHi_[y - yMin], x);
+    }
 
     std::vector<signed char> codes;
     std::vector<std::vector<cv::Point>> found; // discovery order
-    size_t k = 0;
-    const size_t n = idx.size();
-    while (k < n) {
-        // [k, e) = the foreground pixels of one image row (sorted by x)
-        const int y = (int)(idx[k] / W);
-        size_t e = k;
-        while (e < n && (int)(idx[e] / W) == y)
-            ++e;
-        const int xFirst = (int)(idx[k] % W) + 1, xLast = (int)(idx[e - 1] % W) + 1; // padded coords
+    for (int y = yMin; y <= yMax; ++y) {
+        if (rowHi_[y - yMin] < 0)
+            continue;
+        const int xFirst = rowLo_[y - yMin] + 1, xLast = rowHi_[y - yMin] + 1; // padded coordinates
         signed char *row = img + (size_t)(y + 1) * step;
         int lnbd = 0, prev = 0;
         for (int x = xFirst; x <= xLast + 1; ++x) {
@@ -227,7 +235,6 @@ void ContourFinder::find(std::vector<uint32_t> &idx, int W, int H,
             if (prev & -2)
                 lnbd = x;
         }
-        k = e;
     }
     for (uint32_t i : idx)
         img[(size_t)(i / W + 1) * step + (i % W + 1)] = 0;

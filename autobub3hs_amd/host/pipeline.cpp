@@ -305,7 +305,7 @@ public:
             throw std::runtime_error("RunPipeline: bad geometry");
         HIPOK(hipSetDevice(device));
         const char *eg = getenv("ABUB_PIPE_GROUPS");
-        ngroups = eg ? atoi(eg) : 2;
+        ngroups = eg ? atoi(eg) : 1; // >1 overlaps host stages of one group with the GPU work of the next
         int prLow = 0, prHigh = 0; // (numerically lower = higher priority)
         HIPOK(hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
         HIPOK(hipStreamCreateWithPriority(&stage1Stream, hipStreamNonBlocking, prLow));

@@ -32,12 +32,13 @@ int binarizeThresholdFromHist(const uint32_t hist[256], size_t totalPixels, int 
 class ContourFinder {
 public:
     ContourFinder() : w_(0), h_(0) {}
-    // idx: raster indices (y*W+x) of the foreground pixels, any order (sorted in place).
+    // idx: raster indices (y*W+x) of the foreground pixels, in any order.
     void find(std::vector<uint32_t> &idx, int W, int H, std::vector<std::vector<cv::Point>> &contours);
 
 private:
     void traceBorder(size_t start, std::vector<signed char> &codes);
     std::vector<signed char> plane_;
+    std::vector<int> rowLo_, rowHi_; // x-span of the foreground per touched row
     int w_, h_;
 };
 
