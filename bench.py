@@ -54,13 +54,21 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
         sys.exit(2)
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    local = local % ndev  # (rehearsals of N ranks on a smaller box share devices; see ABUB_BENCH_BACKEND)
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     dist = None
+    backend = os.environ.get("ABUB_BENCH_BACKEND", "nccl")  # nccl == RCCL on ROCm; gloo only for rehearsals
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
 
     W, H, F, E, C = args.width, args.height, args.frames, args.events, args.cams
     P = W * H
@@ -96,7 +104,7 @@ def main():
     from autobub3hs_amd import host
 
     tss = [2 * min(args.train_events, E)] * C
-    pipe = host.Pipeline(local, W, H, F, E, C, tss, nthreads=args.threads)
+    pipe = host.Pipeline(local, W, H, F, E, C, tss, nthreads=max(1, args.threads))
     stream = torch.cuda.current_stream().cuda_stream
     njobs = S * (F - 1)
 
@@ -120,7 +128,7 @@ def main():
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
-    dt = shard.max_over_ranks(time.perf_counter() - t1, dev)
+    dt = shard.max_over_ranks(time.perf_counter() - t1, dev if backend == "nccl" else None)
     assert pipe.summary() == fingerprint, "results changed between steps"
     n_trig = sum(1 for r in fingerprint if r[0] == 0)
     n_bub = sum(r[2] for r in fingerprint)
