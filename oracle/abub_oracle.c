@@ -264,7 +264,7 @@ int orc_otsu(const uint32_t h[256], size_t P)
 int orc_binarize(const uint8_t *img, int W, int H, int thr, uint8_t *mask)
 {
     size_t P = (size_t)W * H;
-    uint8_t *t = (uint8_t *)malloc(P);
+    uint8_t *t = (uint8_t *)calloc(P, 1);
     for (size_t i = 0; i < P; i++)
         t[i] = img[i] > thr ? img[i] : 0;
     uint32_t h[256];

@@ -298,3 +298,45 @@ def test_streamed_pipeline_equals_resident(oracle):
         ref = oracle_event(oracle, slab[s // C, s % C], models[s % C][0], models[s % C][1], 16)
         assert (streamed[s][0], streamed[s][1]) == (ref[0], ref[1])
     pipe.close()
+
+
+@pytest.mark.parametrize("W,H", [(1280, 1024), (1680, 1050)])  # BASELINE.json's two camera geometries, full frames
+def test_full_frame_geometries_equal_oracle(oracle, W, H):
+    """Whole (event, camera) analyses at the real frame sizes: frames and the trained model are generated in HBM
+    (synth is integer-only, so torch == numpy), the batched pipeline runs them, and every stack is checked against
+    the oracle on the very same bytes (model included: K1 must equal the oracle's Welford)."""
+    from autobub3hs_amd import hip
+
+    dev = "cuda:0"
+    F, E, C = 41, 3, 2
+    d_slab = torch.empty((E, C, F, H, W), dtype=torch.uint8, device=dev)
+    for e in range(E):
+        for c in range(C):
+            spec = synth.random_spec(W, H, F, 40 + e, c, p_second=0.5, p_none=0.0, p_flicker=0.5, margin=40)
+            synth.render_event(W, H, spec, 40 + e, c, xp="torch", device=dev, out=d_slab[e, c])
+    mus, sgs, tss = [], [], []
+    for c in range(C):
+        tr = synth.training_pairs(W, H, 6, c, F, xp="torch", device=dev)
+        mu, sg = hip.train(tr, W, H)
+        mu_o, sg_o = oracle.welford(tr.cpu().numpy())
+        assert np.array_equal(mu.cpu().numpy(), mu_o) and np.array_equal(sg.cpu().numpy(), sg_o)
+        mus.append(mu), sgs.append(sg), tss.append(tr.shape[0])
+    d_mu, d_s6 = torch.stack(mus), hip.sigma6(torch.stack(sgs))
+    pipe = host.Pipeline(0, W, H, F, E, C, tss, nthreads=4)
+    pipe.run(d_slab, d_mu, d_s6, torch.cuda.current_stream().cuda_stream)
+    slab = d_slab.cpu().numpy()
+    n_bub = 0
+    for e in range(E):
+        for c in range(C):
+            ref = oracle_event(oracle, slab[e, c], mus[c].cpu().numpy(), sgs[c].cpu().numpy(), tss[c])
+            staged, state, bubbles, err = pipe.result(e * C + c)
+            assert (staged, state) == (ref[0], ref[1]), (e, c, staged, state, ref[0], ref[1], err)
+            assert len(bubbles) == len(ref[2])
+            for b, r in zip(bubbles, ref[2]):
+                assert [tuple(d[k] for k in "xywh") for d in b["desc"]] == [tuple(d[k] for k in "xywh") for d in r["desc"]]
+                for d, q in zip(b["desc"], r["desc"]):
+                    assert abs(d["cx"] - q["cx"]) <= 1e-4 and abs(d["cy"] - q["cy"]) <= 1e-4
+                assert b["dzdt"] == pytest.approx(r["dzdt"], nan_ok=True) and b["drdt"] == pytest.approx(r["drdt"], nan_ok=True)
+            n_bub += len(ref[2])
+    assert n_bub >= E * C  # every stack holds at least one bubble
+    pipe.close()
