@@ -283,18 +283,10 @@ struct K2Row {
     uint32_t hp[2 * NDW], hn[2 * NDW]; // horizontally filtered row, both planes
 };
 
-// one input row -> one output row (valid once 5 rows went in)
-template <int NDW, bool STORE, bool COMPACT>
-__device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, K2Row<NDW> &Hcur,
-                                       const K2Row<NDW> &Hprev, bool emit, bool active,
-                                       bool first_lane, bool last_lane, uint32_t *lh,
-                                       uint32_t *__restrict__ po, const Compact &cp, uint32_t pix0)
+// pos / neg planes of one row as u16 pairs (AnalyzerUnit.cpp:351-352)
+template <int NDW>
+__device__ __forceinline__ void k2_planes(const RowIn<NDW> &in, uint32_t (&Xp)[2 * NDW], uint32_t (&Xn)[2 * NDW])
 {
-    constexpr int NP = 2 * NDW;
-    // ---- pos / neg planes as u16 pairs (AnalyzerUnit.cpp:351-352) -----------------------------
-    // sat(sat(c - r) - s) == sat(c - (r + s)) for s >= 0, and r + s <= 510 fits the u16 lane: one plain
-    // 32-bit add (VOP2) + one saturating packed subtract per plane instead of two packed subtracts
-    uint32_t Xp[NP], Xn[NP];
 #pragma unroll
     for (int d = 0; d < NDW; d++) {
         uint32_t c0 = widen_lo(in.c[d]), c1 = widen_hi(in.c[d]);
@@ -304,6 +296,40 @@ __device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, K2Ro
         Xn[2 * d] = pk_subsat(r0, c0 + s0);
         Xp[2 * d + 1] = pk_subsat(c1, r1 + s1);
         Xn[2 * d + 1] = pk_subsat(r1, c1 + s1);
+    }
+}
+// one input row -> one output row (valid once 5 rows went in)
+template <int NDW, bool STORE, bool COMPACT>
+__device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, K2Row<NDW> &Hcur,
+                                       const K2Row<NDW> &Hprev, bool emit, bool active,
+                                       bool first_lane, bool last_lane, uint32_t *lh,
+                                       uint32_t *__restrict__ po, const Compact &cp, uint32_t pix0, int &zrun)
+{
+    constexpr int NP = 2 * NDW;
+    // sat(sat(c - r) - s) == sat(c - (r + s)) for s >= 0, and r + s <= 510 fits the u16 lane: one plain
+    // 32-bit add (VOP2) + one saturating packed subtract per plane instead of two packed subtracts
+    uint32_t Xp[NP], Xn[NP];
+    k2_planes<NDW>(in, Xp, Xn);
+
+    // ---- zero-run shortcut (wave-uniform) ------------------------------------------------------
+    // A row whose pos and neg planes vanish on every lane filters to H = 0, and after four such rows the
+    // whole vertical state (a0,a1,a2 and both H sets) is zero: further zero rows leave it untouched and emit
+    // D = 0, so everything below is skipped.  Static-camera frames spend most of their rows here.
+    {
+        uint32_t nz = 0;
+#pragma unroll
+        for (int j = 0; j < NP; j++)
+            nz |= Xp[j] | Xn[j];
+        const bool rowzero = __builtin_amdgcn_ballot_w64(nz != 0) == 0;
+        if (rowzero && zrun >= 4) {
+            if (STORE && emit && active) {
+#pragma unroll
+                for (int d = 0; d < NDW; d++)
+                    po[d] = 0;
+            }
+            return;
+        }
+        zrun = rowzero ? zrun + 1 : 0;
     }
 
     // ---- horizontal 1-4-6-4-1 (AnalyzerUnit.cpp:359-360; the +128 rounding is applied at the end) ----
@@ -487,6 +513,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER
     // T is rounded up to a multiple of U: the (at most U-1) extra rows re-read the last input row and emit
     // nothing, which keeps the unrolled body free of guards (no phi copies of the ring / accumulators)
     const int Tpad = (T + U - 1) / U * U;
+    int zrun = 4; // the vertical state starts out all zero
     for (int t = 0; t < Tpad; t += U) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -497,7 +524,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER
             k2_row<NDW, STORE, COMPACT>(ring[u % RING], A, HR[u & 1], HR[(u & 1) ^ 1], tt >= 4 && tt < T, active,
                                         first_lane, last_lane, lh,
                                         reinterpret_cast<uint32_t *>(dbase + (ptrdiff_t)y * W), cp,
-                                        (uint32_t)(y * W + xoff));
+                                        (uint32_t)(y * W + xoff), zrun);
         }
     }
 

@@ -43,6 +43,7 @@ int main(int argc, char **argv)
     int F = argc > 1 ? atoi(argv[1]) : 2000, reps = argc > 2 ? atoi(argv[2]) : 5;
     int store = argc > 3 ? atoi(argv[3]) : 0, W = argc > 4 ? atoi(argv[4]) : 1280, H = argc > 5 ? atoi(argv[5]) : 1024;
     int R = argc > 6 ? atoi(argv[6]) : 0;
+    int sig = argc > 7 ? atoi(argv[7]) : 1; // model sigma: 1 -> ~3.5 supra-threshold noise pixels per row, 2 -> none
     size_t P = (size_t)W * H;
     uint8_t *slab, *sigma, *sigma6, *diff = nullptr;
     uint32_t *hist;
@@ -56,7 +57,7 @@ int main(int argc, char **argv)
     if (store)
         CK(hipMalloc(&diff, P * (size_t)njobs));
     hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, slab, P, W, P * F);
-    CK(hipMemset(sigma, 1, P));
+    CK(hipMemset(sigma, sig, P));
     AK(abub_sigma6_dev(sigma, sigma6, P, nullptr));
     std::vector<abub_job> hj(njobs);
     for (int j = 0; j < njobs; j++)
