@@ -1406,8 +1406,7 @@ __global__ __launch_bounds__(256) void k_pairs_scatter(const uint32_t *__restric
     if (n > cap)
         n = cap;
     const uint32_t stride = gridDim.x * blockDim.x;
-    // whole waves iterate together (the loop bound is rounded up per wave) so that the wave-uniform fast
-    // path below is legal: entries of one producer wave-row are contiguous and share their slot
+    // whole waves iterate together (the loop bound is rounded up per wave): the shuffles below need all lanes
     const uint32_t nround = (n + 63u) & ~63u;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += stride) {
         const bool live = i < n;
@@ -1419,20 +1418,21 @@ __global__ __launch_bounds__(256) void k_pairs_scatter(const uint32_t *__restric
             if (s >= nslots)
                 s = 0xffffffffu;
         }
-        const uint32_t s0 = __builtin_amdgcn_readfirstlane(s);
-        const unsigned long long same = __builtin_amdgcn_ballot_w64(s == s0);
-        uint32_t pos;
-        if (same == ~0ull) { // all 64 lanes: one atomic for the wave
-            uint32_t base = 0;
-            if (s0 != 0xffffffffu) {
-                if ((threadIdx.x & 63) == 0)
-                    base = atomicAdd(&cursor[s0], 64u);
-                base = __builtin_amdgcn_readfirstlane(base);
-            }
-            pos = base + (threadIdx.x & 63);
-        } else {
-            pos = s != 0xffffffffu ? atomicAdd(&cursor[s], 1u) : 0;
-        }
+        // one atomic per RUN of equal slots inside the wave (a producer wave-row appends its entries as one
+        // contiguous run): the run's first lane reserves for all of it, the others take their rank in the run
+        const int lane = threadIdx.x & 63;
+        const uint32_t prev = __shfl_up(s, 1);
+        const bool head = lane == 0 || s != prev;
+        const unsigned long long heads = __builtin_amdgcn_ballot_w64(head);
+        const unsigned long long upto = heads & (~0ull >> (63 - lane));   // heads at or below this lane
+        const int leader = 63 - __builtin_clzll(upto);                    // lane 0 is always a head
+        const unsigned long long above = leader < 63 ? heads >> (leader + 1) : 0ull;
+        const int len = above ? __builtin_ctzll(above) + 1 : 64 - leader; // run length
+        uint32_t base = 0;
+        if (head && s != 0xffffffffu)
+            base = atomicAdd(&cursor[s], (uint32_t)len);
+        base = __shfl(base, leader);
+        const uint32_t pos = base + (uint32_t)(lane - leader);
         if (s != 0xffffffffu) {
             idx_out[pos] = w1;
             val_out[pos] = (uint8_t)(w0 >> 24);

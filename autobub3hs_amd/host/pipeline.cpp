@@ -242,7 +242,7 @@ double nowMs()
 struct Group {
     int s0 = 0, s1 = 0; // stacks [s0, s1)
     hipStream_t stream = nullptr;
-    hipEvent_t stage1Done = nullptr;
+    hipEvent_t stage1Done = nullptr, kernelsDone = nullptr;
     abub_job *d_jobs1 = nullptr;
     uint32_t *d_hist1 = nullptr;
     abub_job *d_jobs3 = nullptr;
@@ -272,6 +272,7 @@ public:
     std::vector<Group> groups;
     std::unique_ptr<WorkerPool> pool;
     hipStream_t stage1Stream = nullptr; // all trigger-search launches, in group order (see run())
+    bool ordered = true;                // localisation kernels queue on stage1Stream too (see batchImages())
     std::vector<void *> devAllocs, hostAllocs;
     std::vector<StackState> stacks;
     std::vector<Trainer *> trainers;
@@ -306,6 +307,8 @@ public:
         HIPOK(hipSetDevice(device));
         const char *eg = getenv("ABUB_PIPE_GROUPS");
         ngroups = eg ? atoi(eg) : 1; // >1 overlaps host stages of one group with the GPU work of the next
+        const char *eo = getenv("ABUB_PIPE_ORDERED");
+        ordered = eo ? atoi(eo) != 0 : true;
         int prLow = 0, prHigh = 0; // (numerically lower = higher priority)
         HIPOK(hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
         HIPOK(hipStreamCreateWithPriority(&stage1Stream, hipStreamNonBlocking, prLow));
@@ -329,6 +332,7 @@ public:
             // chip-filling trigger search
             HIPOK(hipStreamCreateWithPriority(&G.stream, hipStreamNonBlocking, prHigh));
             HIPOK(hipEventCreateWithFlags(&G.stage1Done, hipEventDisableTiming));
+            HIPOK(hipEventCreateWithFlags(&G.kernelsDone, hipEventDisableTiming));
             G.d_jobs1 = dalloc<abub_job>(n1);
             G.d_hist1 = dalloc<uint32_t>(n1 * 256);
             G.d_jobs3 = dalloc<abub_job>(n3);
@@ -384,6 +388,8 @@ public:
                 (void)hipStreamDestroy(G.stream);
             if (G.stage1Done)
                 (void)hipEventDestroy(G.stage1Done);
+            if (G.kernelsDone)
+                (void)hipEventDestroy(G.kernelsDone);
         }
         if (stage1Stream)
             (void)hipStreamDestroy(stage1Stream);
@@ -681,7 +687,12 @@ private:
     void batchImages(Group &G, const std::vector<int> &loc, const uint8_t *d_frames, const uint8_t *d_mu,
                      const uint8_t *d_sigma6)
     {
-        hipStream_t stream = G.stream;
+        // Kernels go to `stream`, results come back on the group's own stream.  Ordered mode (default): every
+        // group's kernels queue on the one trigger-search stream, so the GPU sees K2(g0) K2(g1) .. S3(g0) S3(g1) ..
+        // strictly one kernel at a time -- chip-filling kernels launched on different streams only slow each
+        // other down -- while the host stages of group g run under the kernels of group g+1.
+        hipStream_t stream = ordered ? stage1Stream : G.stream;
+        hipStream_t back = G.stream;
         // slots: all genesis images first (K2), then all post-trigger images (K3)
         int nd = 0, np = 0;
         for (int s : loc)
@@ -738,10 +749,12 @@ private:
         check(abub_pairs_group_hist_dev(G.d_pairs, G.d_count, G.pairCap, nimg, G.d_gscratch, G.d_goff, G.d_gidx, G.d_gval,
                                         G.d_hist3, G.d_thr, stream),
               "stage3 group");
-        HIPOK(hipMemcpyAsync(G.h_hist3, G.d_hist3, (size_t)nimg * 1024, hipMemcpyDeviceToHost, stream));
-        HIPOK(hipMemcpyAsync(G.h_count, G.d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        HIPOK(hipMemcpyAsync(G.h_goff, G.d_goff, (size_t)(nimg + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        HIPOK(hipStreamSynchronize(stream));
+        HIPOK(hipEventRecord(G.kernelsDone, stream));
+        HIPOK(hipStreamWaitEvent(back, G.kernelsDone, 0));
+        HIPOK(hipMemcpyAsync(G.h_hist3, G.d_hist3, (size_t)nimg * 1024, hipMemcpyDeviceToHost, back));
+        HIPOK(hipMemcpyAsync(G.h_count, G.d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, back));
+        HIPOK(hipMemcpyAsync(G.h_goff, G.d_goff, (size_t)(nimg + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, back));
+        HIPOK(hipStreamSynchronize(back));
         G.tms[5] += nowMs() - ta; // launches + kernels + hist/count D2H
         ta = nowMs();
         const uint32_t cnt = *G.h_count;
@@ -749,8 +762,8 @@ private:
         if (cnt > G.pairCap)
             throw std::runtime_error("RunPipeline: foreground list overflow (dense foreground in too many images)");
         if (cnt) {
-            HIPOK(hipMemcpyAsync(G.h_gidx, G.d_gidx, (size_t)cnt * 4, hipMemcpyDeviceToHost, stream));
-            HIPOK(hipMemcpyAsync(G.h_gval, G.d_gval, (size_t)cnt, hipMemcpyDeviceToHost, stream));
+            HIPOK(hipMemcpyAsync(G.h_gidx, G.d_gidx, (size_t)cnt * 4, hipMemcpyDeviceToHost, back));
+            HIPOK(hipMemcpyAsync(G.h_gval, G.d_gval, (size_t)cnt, hipMemcpyDeviceToHost, back));
         }
         // thresholds (TOZERO + Otsu) on the host from the histograms, while the list travels
         pool->parallelFor(nimg, [&](int k) {
@@ -760,7 +773,7 @@ private:
             p->fgv = G.h_gval + G.h_goff[k];
             p->nfg = G.h_goff[k + 1] - G.h_goff[k];
         });
-        HIPOK(hipStreamSynchronize(stream));
+        HIPOK(hipStreamSynchronize(back));
         G.tms[6] += nowMs() - ta; // list D2H (+ thresholds)
     }
 
