@@ -156,7 +156,8 @@ int abub_ctx_create(abub_ctx **out, int device, int W, int H, int max_frames);
 void abub_ctx_destroy(abub_ctx *ctx);
 
 /* Trainer::CalculateMeanSigmaImageVector on N host frames (Trainer.cpp:316); fills host mu/sigma.
- * The frames go through the ctx slab in blocks, so N is not limited by max_frames. */
+ * N is not limited by max_frames: a training set larger than the ctx slab gets a temporary device slab of
+ * N frames for the call (the Welford recurrence needs every frame of a pixel in order). */
 int abub_ctx_train(abub_ctx *ctx, const uint8_t *const *frames, int N, uint8_t *mu_out,
                    uint8_t *sigma_out);
 /* 256-bin histogram of sat(f1 - f0) (training entropy veto, Trainer.cpp:279-280). */
