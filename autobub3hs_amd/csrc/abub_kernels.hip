@@ -1433,7 +1433,7 @@ __global__ __launch_bounds__(256) void k_pairs_scatter(const uint32_t *__restric
             base = atomicAdd(&cursor[s], (uint32_t)len);
         base = __shfl(base, leader);
         const uint32_t pos = base + (uint32_t)(lane - leader);
-        if (s != 0xffffffffu) {
+        if (s != 0xffffffffu && pos < cap) { // (offsets come from full counts: stay inside the buffers on overflow)
             idx_out[pos] = w1;
             val_out[pos] = (uint8_t)(w0 >> 24);
         }

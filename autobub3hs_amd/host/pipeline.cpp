@@ -274,6 +274,7 @@ public:
     hipStream_t stage1Stream = nullptr; // all trigger-search launches, in group order (see run())
     bool ordered = true;                // localisation kernels queue on stage1Stream too (see batchImages())
     std::vector<void *> devAllocs, hostAllocs;
+    std::mutex allocMu;
     std::vector<StackState> stacks;
     std::vector<Trainer *> trainers;
     MemParser parser;
@@ -286,6 +287,7 @@ public:
     {
         void *p = nullptr;
         HIPOK(hipMalloc(&p, n * sizeof(T) + 256));
+        std::lock_guard<std::mutex> lock(allocMu); // group threads may grow their lists concurrently
         devAllocs.push_back(p);
         return (T *)p;
     }
@@ -294,6 +296,7 @@ public:
     {
         void *p = nullptr;
         HIPOK(hipHostMalloc(&p, n * sizeof(T) + 256, hipHostMallocDefault));
+        std::lock_guard<std::mutex> lock(allocMu);
         hostAllocs.push_back(p);
         return (T *)p;
     }
@@ -327,7 +330,8 @@ public:
             G.s1 = (int)((long long)S * (g + 1) / ngroups);
             const size_t ns = (size_t)(G.s1 - G.s0), n1 = ns * std::max(F - 1, 1), n3 = ns * K;
             G.nthreads = std::max(1, nthreads / ngroups);
-            G.pairCap = (8u << 20) / ngroups;
+            const char *ec = getenv("ABUB_PIPE_PAIRCAP"); // initial candidate-list capacity (grows on demand)
+            G.pairCap = ec && atoi(ec) > 0 ? (uint32_t)atoi(ec) : (8u << 20) / ngroups;
             // the short localisation launches of a finished group must not queue behind the next group's
             // chip-filling trigger search
             HIPOK(hipStreamCreateWithPriority(&G.stream, hipStreamNonBlocking, prHigh));
@@ -720,47 +724,55 @@ private:
                 G.h_thr[p.slot] = p.tozero; // candidate cut = TOZERO threshold, known before the launch
             }
         }
-        HIPOK(hipMemcpyAsync(G.d_jobs3, G.h_jobs3, (size_t)nimg * sizeof(abub_job), hipMemcpyHostToDevice, stream));
-        HIPOK(hipMemcpyAsync(G.d_thr, G.h_thr, (size_t)nimg * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-        HIPOK(hipMemsetAsync(G.d_count, 0, sizeof(uint32_t), stream));
-        const bool fused = abub_fast_path(W) != 0;
-        if (fused) {
-            // images are never materialised: histogram + candidate list come out of the same pass
-            check(abub_diff_hist_compact_dev(d_frames, d_sigma6, G.d_jobs3, nd, W, H, G.d_hist3, nullptr, G.d_thr,
-                                             G.d_pairs, G.pairCap, G.d_count, 0, stream),
-                  "stage3 K2 compact");
-            if (np > 0)
-                check(abub_posttrig_compact_dev(d_frames, d_mu, d_sigma6, G.d_jobs3 + nd, np, W, H,
-                                                G.d_hist3 + (size_t)nd * 256, nullptr, G.d_thr + nd, G.d_pairs,
-                                                G.pairCap, G.d_count, (uint32_t)nd, stream),
-                      "stage3 K3 compact");
-        } else {
-            check(abub_diff_hist_dev(d_frames, d_sigma6, G.d_jobs3, nd, W, H, G.d_hist3, G.d_img, 0, stream),
-                  "stage3 K2 store");
-            if (np > 0)
-                check(abub_posttrig_dev(d_frames, d_mu, d_sigma6, G.d_jobs3 + nd, np, W, H, G.d_hist3 + (size_t)nd * 256,
-                                        G.d_img + (size_t)nd * P, stream),
-                      "stage3 K3");
-            check(abub_fg_compact_pairs_dev(G.d_img, nimg, W, H, G.d_thr, G.d_pairs, G.pairCap, G.d_count, stream),
-                  "stage3 K4");
+        uint32_t cnt = 0;
+        for (int attempt = 0;; ++attempt) {
+            HIPOK(hipMemcpyAsync(G.d_jobs3, G.h_jobs3, (size_t)nimg * sizeof(abub_job), hipMemcpyHostToDevice, stream));
+            HIPOK(hipMemcpyAsync(G.d_thr, G.h_thr, (size_t)nimg * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+            HIPOK(hipMemsetAsync(G.d_count, 0, sizeof(uint32_t), stream));
+            const bool fused = abub_fast_path(W) != 0;
+            if (fused) {
+                // images are never materialised: histogram + candidate list come out of the same pass
+                check(abub_diff_hist_compact_dev(d_frames, d_sigma6, G.d_jobs3, nd, W, H, G.d_hist3, nullptr, G.d_thr,
+                                                 G.d_pairs, G.pairCap, G.d_count, 0, stream),
+                      "stage3 K2 compact");
+                if (np > 0)
+                    check(abub_posttrig_compact_dev(d_frames, d_mu, d_sigma6, G.d_jobs3 + nd, np, W, H,
+                                                    G.d_hist3 + (size_t)nd * 256, nullptr, G.d_thr + nd, G.d_pairs,
+                                                    G.pairCap, G.d_count, (uint32_t)nd, stream),
+                          "stage3 K3 compact");
+            } else {
+                check(abub_diff_hist_dev(d_frames, d_sigma6, G.d_jobs3, nd, W, H, G.d_hist3, G.d_img, 0, stream),
+                      "stage3 K2 store");
+                if (np > 0)
+                    check(abub_posttrig_dev(d_frames, d_mu, d_sigma6, G.d_jobs3 + nd, np, W, H, G.d_hist3 + (size_t)nd * 256,
+                                            G.d_img + (size_t)nd * P, stream),
+                          "stage3 K3");
+                check(abub_fg_compact_pairs_dev(G.d_img, nimg, W, H, G.d_thr, G.d_pairs, G.pairCap, G.d_count, stream),
+                      "stage3 K4");
+            }
+            // group the list by image on the device; the host gets contiguous runs and never re-buckets
+            // (per-slot counts come from the histograms the same launches produced: no counting pass)
+            check(abub_pairs_group_hist_dev(G.d_pairs, G.d_count, G.pairCap, nimg, G.d_gscratch, G.d_goff, G.d_gidx, G.d_gval,
+                                            G.d_hist3, G.d_thr, stream),
+                  "stage3 group");
+            HIPOK(hipEventRecord(G.kernelsDone, stream));
+            HIPOK(hipStreamWaitEvent(back, G.kernelsDone, 0));
+            HIPOK(hipMemcpyAsync(G.h_hist3, G.d_hist3, (size_t)nimg * 1024, hipMemcpyDeviceToHost, back));
+            HIPOK(hipMemcpyAsync(G.h_count, G.d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, back));
+            HIPOK(hipMemcpyAsync(G.h_goff, G.d_goff, (size_t)(nimg + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, back));
+            HIPOK(hipStreamSynchronize(back));
+            G.tms[5] += nowMs() - ta; // launches + kernels + hist/count D2H
+            ta = nowMs();
+            cnt = *G.h_count;
+            G.lastPairs = cnt;
+            if (cnt <= G.pairCap)
+                break;
+            // dense foreground (e.g. a flash frame): the kernels kept counting past the capacity, so the needed
+            // size is known -- grow the lists once and redo the batch
+            if (attempt > 0 || cnt > (1u << 30))
+                throw std::runtime_error("RunPipeline: foreground list overflow (dense foreground in too many images)");
+            growLists(G, cnt + cnt / 4 + 1024);
         }
-        // group the list by image on the device; the host gets contiguous runs and never re-buckets
-        // (per-slot counts come from the histograms the same launches produced: no counting pass)
-        check(abub_pairs_group_hist_dev(G.d_pairs, G.d_count, G.pairCap, nimg, G.d_gscratch, G.d_goff, G.d_gidx, G.d_gval,
-                                        G.d_hist3, G.d_thr, stream),
-              "stage3 group");
-        HIPOK(hipEventRecord(G.kernelsDone, stream));
-        HIPOK(hipStreamWaitEvent(back, G.kernelsDone, 0));
-        HIPOK(hipMemcpyAsync(G.h_hist3, G.d_hist3, (size_t)nimg * 1024, hipMemcpyDeviceToHost, back));
-        HIPOK(hipMemcpyAsync(G.h_count, G.d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, back));
-        HIPOK(hipMemcpyAsync(G.h_goff, G.d_goff, (size_t)(nimg + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, back));
-        HIPOK(hipStreamSynchronize(back));
-        G.tms[5] += nowMs() - ta; // launches + kernels + hist/count D2H
-        ta = nowMs();
-        const uint32_t cnt = *G.h_count;
-        G.lastPairs = cnt;
-        if (cnt > G.pairCap)
-            throw std::runtime_error("RunPipeline: foreground list overflow (dense foreground in too many images)");
         if (cnt) {
             HIPOK(hipMemcpyAsync(G.h_gidx, G.d_gidx, (size_t)cnt * 4, hipMemcpyDeviceToHost, back));
             HIPOK(hipMemcpyAsync(G.h_gval, G.d_gval, (size_t)cnt, hipMemcpyDeviceToHost, back));
@@ -775,6 +787,17 @@ private:
         });
         HIPOK(hipStreamSynchronize(back));
         G.tms[6] += nowMs() - ta; // list D2H (+ thresholds)
+    }
+
+    // the old buffers stay on the allocation lists and are released with the pipeline
+    void growLists(Group &G, uint32_t cap)
+    {
+        G.pairCap = cap;
+        G.d_pairs = dalloc<uint32_t>((size_t)cap * 2);
+        G.d_gidx = dalloc<uint32_t>(cap);
+        G.d_gval = dalloc<uint8_t>(cap);
+        G.h_gidx = halloc<uint32_t>(cap);
+        G.h_gval = halloc<uint8_t>(cap);
     }
 
     // AnyCamAnalysis body from LocalizeOMatic on (AutoBubStart3.cpp:94-110)

@@ -340,3 +340,35 @@ def test_full_frame_geometries_equal_oracle(oracle, W, H):
             n_bub += len(ref[2])
     assert n_bub >= E * C  # every stack holds at least one bubble
     pipe.close()
+
+
+def test_candidate_list_grows_on_overflow(oracle):
+    """A candidate-list capacity far below what the batch needs: the pipeline must notice the overflow (the kernels
+    keep counting), grow the lists and redo the batch -- same results as with the default capacity."""
+    from autobub3hs_amd import hip
+
+    dev = "cuda:0"
+    W, H, F, E, C = 1280, 96, 41, 4, 1
+    slab = np.zeros((E, C, F, H, W), np.uint8)
+    for e in range(E):
+        spec = synth.random_spec(W, H, F, 300 + e, 0, p_second=0.5, margin=25)
+        slab[e, 0] = synth.render_event(W, H, spec, 300 + e, 0)
+    mu, sg = oracle.welford(synth.training_pairs(W, H, 8, 0, F))
+    d_slab = torch.from_numpy(slab).to(dev)
+    d_mu = torch.from_numpy(mu[None]).to(dev)
+    d_s6 = hip.sigma6(torch.from_numpy(sg[None]).to(dev))
+    res = []
+    for cap in ("64", None):
+        if cap:
+            os.environ["ABUB_PIPE_PAIRCAP"] = cap
+        try:
+            pipe = host.Pipeline(0, W, H, F, E, C, [16], nthreads=2)
+        finally:
+            os.environ.pop("ABUB_PIPE_PAIRCAP", None)
+        pipe.run(d_slab, d_mu, d_s6, torch.cuda.current_stream().cuda_stream)
+        assert pipe.timing()["pairs"] > 64
+        res.append([pipe.result(s)[:3] for s in range(E * C)])
+        pipe.close()
+    assert repr(res[0]) == repr(res[1])
+    ref = oracle_event(oracle, slab[0, 0], mu, sg, 16)
+    assert (res[0][0][0], res[0][0][1]) == (ref[0], ref[1])
