@@ -982,7 +982,7 @@ __device__ __forceinline__ void k3_load_row(Row3In<NDW> &R, const uint8_t *__res
 template <int NDW, bool STORE>
 __device__ __forceinline__ void k3_row(const Row3In<NDW> &in, uint32_t (&a0)[2 * NDW], uint32_t (&xp)[2 * NDW],
                                        bool emit, bool active, bool first_lane, bool last_lane, uint32_t *lh,
-                                       uint32_t *__restrict__ po, const Compact &cp, uint32_t pix0)
+                                       uint32_t *__restrict__ po, const Compact &cp, uint32_t pix0, int &zrun)
 {
     constexpr int NP = 2 * NDW;
     uint32_t X[NP];
@@ -993,6 +993,24 @@ __device__ __forceinline__ void k3_row(const Row3In<NDW> &in, uint32_t (&a0)[2 *
         uint32_t s0 = widen_lo(in.s[d]), s1 = widen_hi(in.s[d]);
         X[2 * d] = pk_subsat(pk_subsat(f0, m0) | pk_subsat(m0, f0), s0);     // L3Localizer.cpp:779-782
         X[2 * d + 1] = pk_subsat(pk_subsat(f1, m1) | pk_subsat(m1, f1), s1);
+    }
+    // zero-run shortcut (wave-uniform, as in K2): two all-zero rows drain a0 and xp; from then on an all-zero row
+    // changes nothing and emits (0 + 4) / 9 = 0
+    {
+        uint32_t nz = 0;
+#pragma unroll
+        for (int j = 0; j < NP; j++)
+            nz |= X[j];
+        const bool rowzero = __builtin_amdgcn_ballot_w64(nz != 0) == 0;
+        if (rowzero && zrun >= 2) {
+            if (STORE && emit && active) {
+#pragma unroll
+                for (int d = 0; d < NDW; d++)
+                    po[d] = 0;
+            }
+            return;
+        }
+        zrun = rowzero ? zrun + 1 : 0;
     }
     // neighbours: only p[-1] (hi half of L) and p[n] (lo half of R) are used; reflect-101 in-lane
     uint32_t L = __builtin_amdgcn_update_dpp(0u, X[NP - 1], DPP_WAVE_SHR1, 0xf, 0xf, false);
@@ -1108,6 +1126,7 @@ __global__ __launch_bounds__(64) void k3_rows(const uint8_t *__restrict__ frames
 
     Row3In<NDW> ring[2];
     k3_load_row<NDW>(ring[0], f, m, sg, reflect101(y0 - 1, H), W, xoff);
+    int zrun = 2; // the vertical state starts out all zero
     for (int t = 0; t < T; t += 2) {
 #pragma unroll
         for (int u = 0; u < 2; u++) {
@@ -1118,7 +1137,7 @@ __global__ __launch_bounds__(64) void k3_rows(const uint8_t *__restrict__ frames
                 int y = y0 + tt - 2;
                 k3_row<NDW, STORE>(ring[u], a0, xp, tt >= 2, active, first_lane, last_lane, lh,
                                    reinterpret_cast<uint32_t *>(obase + (ptrdiff_t)y * W), cp,
-                                   (uint32_t)(y * W + xoff));
+                                   (uint32_t)(y * W + xoff), zrun);
             }
         }
     }
