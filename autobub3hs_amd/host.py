@@ -383,3 +383,56 @@ class Pipeline:
             L.abh_pipe_result(self._h, s, o)
             out.append((o[0], o[1], o[5]))
         return out
+
+
+class PipelineRing:
+    """N pipeline objects, each driven by its own host thread: batch k runs on pipeline k % N, so the host stages of
+    one batch (trigger state machines, contour tracing, tracking) run while the GPU is busy with the kernels of the
+    next.  Every batch still goes through the complete path; only their stages interleave.  N = 1 is a plain loop."""
+
+    def __init__(self, n, device, W, H, F, E, ncams, tss, nthreads=16, maskdir=""):
+        self.device = device
+        self.pipes = [Pipeline(device, W, H, F, E, ncams, tss, nthreads=nthreads, maskdir=maskdir) for _ in range(max(1, n))]
+
+    def close(self):
+        for p in self.pipes:
+            p.close()
+
+    def run_batches(self, batches, mu, sigma6, stream=0, on_done=None):
+        """batches: sequence of frame slabs (device tensors / pointers, each [E][C][F][H][W]).  Returns the per-batch
+        timing dicts in completion order; `on_done(k, pipeline)` is called on the driving thread right after batch
+        k finished, while its results are still the pipeline's current ones."""
+        import threading
+
+        n = len(self.pipes)
+        tms, errs = [], []
+        lock = threading.Lock()
+
+        def drive(i):
+            try:
+                try:
+                    import torch
+
+                    torch.cuda.set_device(self.device)
+                except ImportError:
+                    pass
+                for k in range(i, len(batches), n):
+                    self.pipes[i].run(batches[k], mu, sigma6, stream)
+                    if on_done:
+                        on_done(k, self.pipes[i])
+                    with lock:
+                        tms.append(self.pipes[i].timing())
+            except BaseException as e:  # noqa: BLE001 -- re-raised on the caller's thread
+                errs.append(e)
+
+        if n == 1:
+            drive(0)
+        else:
+            th = [threading.Thread(target=drive, args=(i,)) for i in range(n)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        if errs:
+            raise errs[0]
+        return tms

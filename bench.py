@@ -7,7 +7,9 @@ has no collective, events shard embarrassingly), rank 0 prints ONE JSON line.
 
 Workload at N=1 (BASELINE.json configs[1], SURVEY.md 8d "Config 2"): one synthetic 40l-19-like run,
 E events x cams {0,1} x F=41 frames of 1280x1024 u8, resident in HBM before the timed region.
-A "step" is one pass of the detect path over the whole run.
+A "step" is one pass of the detect path over the whole run.  Steps are software-pipelined (--inflight, default 3:
+host.PipelineRing): the host stages of step k run while the GPU works on step k+1; all K steps start and finish
+inside the timed region.
 """
 import argparse
 import json
@@ -36,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--threads", type=int, default=16, help="host threads of the per-event state machines")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="steps in flight at once (each on its own pipeline object and host thread)")
     ap.add_argument("--stream-steps", type=int, default=2,
                     help="extra steps with the run uploaded from pinned host memory (PCIe-inclusive rate; 0 = skip)")
     return ap.parse_args()
@@ -104,16 +108,20 @@ def main():
     from autobub3hs_amd import host
 
     tss = [2 * min(args.train_events, E)] * C
-    pipe = host.Pipeline(local, W, H, F, E, C, tss, nthreads=max(1, args.threads))
+    # --inflight N (host.PipelineRing): N pipeline objects, each driven by its own host thread; step k runs on pipeline
+    # k % N, so the host stages of one step (state machines, contours) overlap the GPU stages of the next.  Every step
+    # is still a full pass over the same batch, and all K of them complete inside the timed region.
+    ninfl = max(1, args.inflight)
+    ring = host.PipelineRing(ninfl, local, W, H, F, E, C, tss, nthreads=max(1, args.threads))
+    pipes = ring.pipes
+    pipe = pipes[0]
     stream = torch.cuda.current_stream().cuda_stream
     njobs = S * (F - 1)
 
-    def step():
-        pipe.run(slab, mu_d, s6_d, stream)
-        return pipe.timing()
+    def run_steps(n):
+        return ring.run_batches([slab] * n, mu_d, s6_d, stream)
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(max(args.warmup, ninfl if args.warmup else 0))
     fingerprint = pipe.summary()
     if dist:
         dist.barrier()
@@ -121,15 +129,15 @@ def main():
     t1 = time.perf_counter()
     stage = {"stage1_ms": 0.0, "stage2_ms": 0.0, "stage3_ms": 0.0, "stage4_ms": 0.0, "total_ms": 0.0, "s3_gpu_ms": 0.0,
              "s3_list_ms": 0.0, "s3_bucket_ms": 0.0, "pairs": 0.0, "rounds": 0}
-    for k in range(args.steps):
-        tm = step()
+    for tm in run_steps(args.steps):
         for kk in stage:
             stage[kk] += tm[kk]
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     dt = shard.max_over_ranks(time.perf_counter() - t1, dev if backend == "nccl" else None)
-    assert pipe.summary() == fingerprint, "results changed between steps"
+    for p_ in pipes[:max(1, min(ninfl, args.steps))]:
+        assert p_.summary() == fingerprint, "results changed between steps"
     n_trig = sum(1 for r in fingerprint if r[0] == 0)
     n_bub = sum(r[2] for r in fingerprint)
 
@@ -199,6 +207,8 @@ def main():
             "events_per_gpu": E, "cams": C, "frames_per_stack": F, "width": W, "height": H,
             "parallelism": f"events sharded over {world} GPU(s), no collective",
             "host_threads": args.threads,
+            "steps_in_flight": ninfl,  # stage_ms below are wall times inside one step: with >1 in flight they include
+                                       # queueing behind the other steps' kernels and no longer add up to ms_per_step
             "triggered_stacks": n_trig, "bubbles": n_bub,
             "stage_ms": {k: round(v / args.steps, 3) for k, v in stage.items()},
             "gen_seconds": round(gen_s, 1),

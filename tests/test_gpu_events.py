@@ -372,3 +372,38 @@ def test_candidate_list_grows_on_overflow(oracle):
     assert repr(res[0]) == repr(res[1])
     ref = oracle_event(oracle, slab[0, 0], mu, sg, 16)
     assert (res[0][0][0], res[0][0][1]) == (ref[0], ref[1])
+
+
+def test_pipeline_ring_batches_in_flight(oracle):
+    """Three batches in flight on a ring of three pipelines (host stages of one under the GPU stages of the next):
+    every batch must come out exactly as from a single pipeline, whichever pipeline object served it."""
+    from autobub3hs_amd import hip
+
+    dev = "cuda:0"
+    W, H, F, E, C = 1280, 96, 41, 3, 2
+    batches = []
+    for b in range(5):
+        slab = np.zeros((E, C, F, H, W), np.uint8)
+        for e in range(E):
+            for c in range(C):
+                spec = synth.random_spec(W, H, F, 600 + 10 * b + e, c, p_second=0.3, p_none=0.2, margin=25)
+                slab[e, c] = synth.render_event(W, H, spec, 600 + 10 * b + e, c)
+        batches.append(slab)
+    models = [oracle.welford(synth.training_pairs(W, H, 8, c, F)) for c in range(C)]
+    d_mu = torch.from_numpy(np.stack([m[0] for m in models])).to(dev)
+    d_s6 = hip.sigma6(torch.from_numpy(np.stack([m[1] for m in models])).to(dev))
+    d_batches = [torch.from_numpy(b).to(dev) for b in batches]
+    single = host.Pipeline(0, W, H, F, E, C, [16, 16], nthreads=2)
+    want = []
+    for db in d_batches:
+        single.run(db, d_mu, d_s6, torch.cuda.current_stream().cuda_stream)
+        want.append(repr([single.result(s)[:3] for s in range(E * C)]))
+    single.close()
+    ring = host.PipelineRing(3, 0, W, H, F, E, C, [16, 16], nthreads=2)
+    got = {}
+    tms = ring.run_batches(d_batches, d_mu, d_s6, torch.cuda.current_stream().cuda_stream,
+                           on_done=lambda k, p: got.__setitem__(k, repr([p.result(s)[:3] for s in range(E * C)])))
+    ring.close()
+    assert len(tms) == 5 and [got[k] for k in range(5)] == want
+    ref = oracle_event(oracle, batches[4][1, 1], models[1][0], models[1][1], 16)
+    assert eval(got[4], {"nan": float("nan")})[1 * C + 1][:2] == (ref[0], ref[1])
