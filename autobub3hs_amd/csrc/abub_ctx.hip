@@ -102,6 +102,7 @@ extern "C" void abub_ctx_destroy(abub_ctx *c)
     (void)hipHostFree(c->h_job);
     (void)hipHostFree(c->h_small);
     (void)hipHostFree(c->h_idx);
+    (void)abub_scratch_release(c->stream);
     (void)hipStreamDestroy(c->stream);
     free(c);
 }

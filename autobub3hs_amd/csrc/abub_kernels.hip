@@ -15,6 +15,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "../../include/abub_hip.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -298,6 +302,42 @@ __device__ __forceinline__ void k2_planes(const RowIn<NDW> &in, uint32_t (&Xp)[2
         Xn[2 * d + 1] = pk_subsat(r1, c1 + s1);
     }
 }
+// horizontal 1-4-6-4-1 of one row, both planes (AnalyzerUnit.cpp:359-360; the +128 rounding is applied at the end)
+template <int NDW>
+__device__ __forceinline__ void k2_hpass(const uint32_t (&Xp)[2 * NDW], const uint32_t (&Xn)[2 * NDW], bool first_lane,
+                                         bool last_lane, uint32_t (&Hp)[2 * NDW], uint32_t (&Hn)[2 * NDW])
+{
+    constexpr int NP = 2 * NDW;
+    // left pair (p[-2],p[-1]) and right pair (p[n],p[n+1]): neighbour lanes, reflect-101 at the edges
+    uint32_t reflLp = __builtin_amdgcn_perm(Xp[0], Xp[1], 0x07060100u); // (X1.lo, X0.hi) = (p2,p1)
+    uint32_t reflLn = __builtin_amdgcn_perm(Xn[0], Xn[1], 0x07060100u);
+    uint32_t reflRp = __builtin_amdgcn_perm(Xp[NP - 2], Xp[NP - 1], 0x07060100u); // (p[n-2],p[n-3])
+    uint32_t reflRn = __builtin_amdgcn_perm(Xn[NP - 2], Xn[NP - 1], 0x07060100u);
+    uint32_t Lp = __builtin_amdgcn_update_dpp(0u, Xp[NP - 1], DPP_WAVE_SHR1, 0xf, 0xf, false);
+    uint32_t Ln = __builtin_amdgcn_update_dpp(0u, Xn[NP - 1], DPP_WAVE_SHR1, 0xf, 0xf, false);
+    uint32_t Rp = __builtin_amdgcn_update_dpp(0u, Xp[0], DPP_WAVE_SHL1, 0xf, 0xf, false);
+    uint32_t Rn = __builtin_amdgcn_update_dpp(0u, Xn[0], DPP_WAVE_SHL1, 0xf, 0xf, false);
+    Lp = first_lane ? reflLp : Lp;
+    Ln = first_lane ? reflLn : Ln;
+    Rp = last_lane ? reflRp : Rp;
+    Rn = last_lane ? reflRn : Rn;
+    uint32_t am1p = __builtin_amdgcn_alignbit(Xp[0], Lp, 16); // (p[-1], p[0])
+    uint32_t am1n = __builtin_amdgcn_alignbit(Xn[0], Ln, 16);
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        uint32_t xm1p = j ? Xp[j - 1] : Lp, xp1p = j + 1 < NP ? Xp[j + 1] : Rp;
+        uint32_t xm1n = j ? Xn[j - 1] : Ln, xp1n = j + 1 < NP ? Xn[j + 1] : Rn;
+        uint32_t ap1p = __builtin_amdgcn_alignbit(xp1p, Xp[j], 16); // (p[2j+1], p[2j+2])
+        uint32_t ap1n = __builtin_amdgcn_alignbit(xp1n, Xn[j], 16);
+        uint32_t sp = am1p + ap1p, sn = am1n + ap1n;
+        uint32_t tp = xm1p + xp1p, tn = xm1n + xp1n;
+        Hp[j] = pk_madk<6>(Xp[j], (sp << 2) + tp); // every u16 lane <= 4080
+        Hn[j] = pk_madk<6>(Xn[j], (sn << 2) + tn);
+        am1p = ap1p;
+        am1n = ap1n;
+    }
+}
+
 // one input row -> one output row (valid once 5 rows went in)
 template <int NDW, bool STORE, bool COMPACT>
 __device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, K2Row<NDW> &Hcur,
@@ -333,39 +373,9 @@ __device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, K2Ro
     }
 
     // ---- horizontal 1-4-6-4-1 (AnalyzerUnit.cpp:359-360; the +128 rounding is applied at the end) ----
-    // left pair (p[-2],p[-1]) and right pair (p[n],p[n+1]): neighbour lanes, reflect-101 at the edges
-    uint32_t reflLp = __builtin_amdgcn_perm(Xp[0], Xp[1], 0x07060100u); // (X1.lo, X0.hi) = (p2,p1)
-    uint32_t reflLn = __builtin_amdgcn_perm(Xn[0], Xn[1], 0x07060100u);
-    uint32_t reflRp = __builtin_amdgcn_perm(Xp[NP - 2], Xp[NP - 1], 0x07060100u); // (p[n-2],p[n-3])
-    uint32_t reflRn = __builtin_amdgcn_perm(Xn[NP - 2], Xn[NP - 1], 0x07060100u);
-    uint32_t Lp = __builtin_amdgcn_update_dpp(0u, Xp[NP - 1], DPP_WAVE_SHR1, 0xf, 0xf, false);
-    uint32_t Ln = __builtin_amdgcn_update_dpp(0u, Xn[NP - 1], DPP_WAVE_SHR1, 0xf, 0xf, false);
-    uint32_t Rp = __builtin_amdgcn_update_dpp(0u, Xp[0], DPP_WAVE_SHL1, 0xf, 0xf, false);
-    uint32_t Rn = __builtin_amdgcn_update_dpp(0u, Xn[0], DPP_WAVE_SHL1, 0xf, 0xf, false);
-    Lp = first_lane ? reflLp : Lp;
-    Ln = first_lane ? reflLn : Ln;
-    Rp = last_lane ? reflRp : Rp;
-    Rn = last_lane ? reflRn : Rn;
-
     uint32_t(&Hp)[NP] = Hcur.hp;
     uint32_t(&Hn)[NP] = Hcur.hn;
-    {
-        uint32_t am1p = __builtin_amdgcn_alignbit(Xp[0], Lp, 16); // (p[-1], p[0])
-        uint32_t am1n = __builtin_amdgcn_alignbit(Xn[0], Ln, 16);
-#pragma unroll
-        for (int j = 0; j < NP; j++) {
-            uint32_t xm1p = j ? Xp[j - 1] : Lp, xp1p = j + 1 < NP ? Xp[j + 1] : Rp;
-            uint32_t xm1n = j ? Xn[j - 1] : Ln, xp1n = j + 1 < NP ? Xn[j + 1] : Rn;
-            uint32_t ap1p = __builtin_amdgcn_alignbit(xp1p, Xp[j], 16); // (p[2j+1], p[2j+2])
-            uint32_t ap1n = __builtin_amdgcn_alignbit(xp1n, Xn[j], 16);
-            uint32_t sp = am1p + ap1p, sn = am1n + ap1n;
-            uint32_t tp = xm1p + xp1p, tn = xm1n + xp1n;
-            Hp[j] = pk_madk<6>(Xp[j], (sp << 2) + tp); // every u16 lane <= 4080
-            Hn[j] = pk_madk<6>(Xn[j], (sn << 2) + tn);
-            am1p = ap1p;
-            am1n = ap1n;
-        }
-    }
+    k2_hpass<NDW>(Xp, Xn, first_lane, last_lane, Hp, Hn);
 
     // ---- vertical 1-4-6-4-1, (S+128)>>8, absdiff (AnalyzerUnit.cpp:370) -----------------------
     uint32_t Vp[NP], Vn[NP];
@@ -450,13 +460,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER
                                               int rows_per_chunk, int nchunks,
                                               uint32_t *__restrict__ hist, uint8_t *__restrict__ diff,
                                               const int32_t *__restrict__ cthr, uint32_t *pairs,
-                                              uint32_t pcap, uint32_t *pcount, uint32_t slot_base)
+                                              uint32_t pcap, uint32_t *pcount, uint32_t slot_base,
+                                              const uint2 *__restrict__ unit_list,
+                                              const uint32_t *__restrict__ unit_count)
 {
     constexpr int NP = 2 * NDW; // u16-pair registers per plane per lane
     __shared__ uint32_t lh[256];
 
     const int lane = threadIdx.x;
-    const int unit = blockIdx.x;
+    // list mode (bound-and-verify hand-over): the grid strides over the listed units; otherwise unit = block
+    const uint32_t nunits_ = unit_list ? *unit_count : gridDim.x;
+    for (uint32_t ui = blockIdx.x; ui < nunits_; ui += gridDim.x) {
+    const int unit = unit_list ? (int)unit_list[ui].x : (int)ui;
     const int job = unit / nchunks;
     const int chunk = unit - job * nchunks; // chunk fastest: unit % 8 == chunk % 8 when nchunks % 8 == 0
     const abub_job jb = jobs[job];
@@ -470,8 +485,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER
     const bool last_lane = lane == nl - 1;
     const int xoff = active ? lane * 4 * NDW : 0; // idle lanes shadow lane 0 (results unused)
 
-    const int y0 = chunk * rows_per_chunk;
-    int y1 = y0 + rows_per_chunk;
+    const int y0 = unit_list ? (int)unit_list[ui].y : chunk * rows_per_chunk; // list mode: the rows left over
+    int y1 = (chunk + 1) * rows_per_chunk;
     if (y1 > H)
         y1 = H;
     const int T = y1 - y0 + 4; // input rows y0-2 .. y1+1 (reflected)
@@ -535,6 +550,231 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER
         uint32_t v = lh[lane + 64 * k];
         if (v && (lane + 64 * k))
             atomicAdd(&gh[lane + 64 * k], v);
+    }
+    __syncthreads(); // lh is zeroed again by the next unit
+    } // units
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 trigger-only, "bound and verify".  The trigger search only needs the histogram of D, and D(y,x) != 0 needs a
+// 5x5 weighted sum S >= 128 in one plane.  With X = pos + neg (disjoint supports, so both plane sums are <= the sum
+// over X) and the lane's pixels in groups of four columns:
+//     S(y,x) <= sum_i w_i * 6 * M_g(y+i),   M_g(r) = m_{g-1}(r) + m_g(r) + m_{g+1}(r),   m_g = mass of X in group g
+// (every tap of the horizontal filter is <= 6 and reaches at most the neighbouring group; at the image edges the
+// reflected columns fall into the edge group itself, which the edge-replicated m_{-1} = m_0 counts a second time).
+//   k2_bound_scan   one wave per (job, chunk) carries only this bound down the rows -- the same 1-4-6-4-1 recurrence,
+//                   but on NDW packed group masses per lane instead of 4*NDW filtered pairs in two planes (70 VGPRs,
+//                   7 waves/SIMD: the pass runs at what the memory system can feed) -- and proves "D is zero" for
+//                   whole rows with one ballot.  Groups it cannot prove go to a list (LDS first, one global
+//                   reservation per chunk); a chunk with more than K2B_PEND of them (a big bubble, or dense
+//                   foreground) is handed over whole instead.
+//   k2_exact_groups one lane per listed (job, row, group): the four pixels of D exactly, from their 5 x 8 inputs.
+//   k2_rows (list)  the full row machine on the chunks handed over whole.
+// Every pixel is either proven zero or computed with the reference arithmetic, and never twice (a chunk that is
+// handed over drops its pending groups): the histogram is bit-identical to the plain k2_rows pass.
+// Packed halves: a register holds (mass of columns 0,2 | mass of columns 1,3) of a group; all recurrences are linear
+// and stay < 65536 per half (<= 16 * 3 * 2 * 255); the row test folds max-of-halves over the lane's groups, which
+// can only over-estimate, the per-group test on a suspicious row folds exactly.
+// ------------------------------------------------------------------------------------------------
+#define K2B_PEND 512 /* >= the groups of one row (W/4 <= 512) */
+
+template <int NDW>
+__global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ frames,
+                                                    const uint8_t *__restrict__ sigma6,
+                                                    const abub_job *__restrict__ jobs, int W, int H,
+                                                    int rows_per_chunk, int nchunks, uint2 *__restrict__ list,
+                                                    uint32_t *__restrict__ nlist, uint32_t budget,
+                                                    uint2 *__restrict__ units, uint32_t *__restrict__ nunits)
+{
+    constexpr int NP = 2 * NDW;
+    __shared__ uint32_t pend[K2B_PEND];
+    const int lane = threadIdx.x;
+    const int unit = blockIdx.x;
+    const int job = unit / nchunks;
+    const int chunk = unit - job * nchunks;
+    const abub_job jb = jobs[job];
+    const size_t P = (size_t)W * H;
+    const uint8_t *cur = frames + (size_t)jb.cur * P;
+    const uint8_t *ref = frames + (size_t)jb.ref * P;
+    const uint8_t *sg = sigma6 + (size_t)jb.model * P;
+    const int nl = W / (4 * NDW);
+    const bool active = lane < nl;
+    const bool first_lane = lane == 0;
+    const bool last_lane = lane == nl - 1;
+    const int xoff = active ? lane * 4 * NDW : 0;
+    const int y0 = chunk * rows_per_chunk;
+    int y1 = y0 + rows_per_chunk;
+    if (y1 > H)
+        y1 = H;
+    const int T = y1 - y0 + 4; // input rows y0-2 .. y1+1 (reflected); step tt bounds output row y0+tt-4
+    const uint32_t ngroups = (uint32_t)W / 4;
+
+    uint32_t b0[NDW], b1[NDW], b2[NDW], Mprev[NDW];
+#pragma unroll
+    for (int g = 0; g < NDW; g++)
+        b0[g] = b1[g] = b2[g] = Mprev[g] = 0;
+    uint32_t npend = 0, spent = 0, hot = 0; // wave-uniform: pending in LDS, already flushed, rows with many suspects
+    int handover = -1;                      // first output row left to the row machine
+    // The list has room for `budget` entries per chunk, so a reservation can never overflow it.
+    auto flush = [&]() {
+        if (npend == 0)
+            return;
+        __syncthreads(); // (one wave: orders the LDS writes before the reads below)
+        uint32_t base = 0;
+        if (lane == 0)
+            base = atomicAdd(nlist, npend);
+        base = __shfl(base, 0);
+        for (uint32_t i = lane; i < npend; i += 64)
+            list[base + i] = make_uint2((uint32_t)job, pend[i]);
+        __syncthreads();
+        spent += npend;
+        npend = 0;
+    };
+
+    RowIn<NDW> ring[2];
+    k2_load_row<NDW>(ring[0], cur, ref, sg, reflect101(y0 - 2, H), W, xoff);
+    const int Tpad = (T + 1) & ~1;
+    for (int t = 0; t < Tpad && handover < 0; t += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int tt = t + u;
+            int tn = tt + 1 < T ? tt + 1 : T - 1;
+            k2_load_row<NDW>(ring[u ^ 1], cur, ref, sg, reflect101(y0 - 2 + tn, H), W, xoff);
+            uint32_t Xp[NP], Xn[NP];
+            k2_planes<NDW>(ring[u], Xp, Xn);
+            uint32_t m[NDW];
+#pragma unroll
+            for (int g = 0; g < NDW; g++)
+                m[g] = (Xp[2 * g] + Xn[2 * g]) + (Xp[2 * g + 1] + Xn[2 * g + 1]);
+            uint32_t mL = __builtin_amdgcn_update_dpp(0u, m[NDW - 1], DPP_WAVE_SHR1, 0xf, 0xf, false);
+            uint32_t mR = __builtin_amdgcn_update_dpp(0u, m[0], DPP_WAVE_SHL1, 0xf, 0xf, false);
+            mL = first_lane ? m[0] : mL;
+            mR = last_lane ? m[NDW - 1] : mR;
+            uint32_t B[NDW];
+            uint32_t worst = 0;
+#pragma unroll
+            for (int g = 0; g < NDW; g++) {
+                const uint32_t M = (g ? m[g - 1] : mL) + m[g] + (g + 1 < NDW ? m[g + 1] : mR);
+                B[g] = b0[g] + M; // bound / 6 of output row tt-4 for the columns of group g
+                const uint32_t M4 = M << 2;
+                b0[g] = b1[g] + M4;
+                b1[g] = pk_madk<6>(M, b2[g]);
+                b2[g] = Mprev[g] + M4;
+                Mprev[g] = M;
+                u16x2 w = __builtin_bit_cast(u16x2, worst), bb = __builtin_bit_cast(u16x2, B[g]);
+                worst = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(w, bb));
+            }
+            // 6 * (lo + hi) < 128  <=>  lo + hi <= 21
+            const bool unsure = active && ((worst & 0xffffu) + (worst >> 16)) > 21u;
+            if (tt >= 4 && tt < T && handover < 0 && __builtin_amdgcn_ballot_w64(unsure)) {
+                uint32_t fmask = 0;
+                if (active) {
+#pragma unroll
+                    for (int g = 0; g < NDW; g++)
+                        if ((B[g] & 0xffffu) + (B[g] >> 16) > 21u)
+                            fmask |= 1u << g;
+                }
+                const uint32_t c = __builtin_popcount(fmask);
+                uint32_t inc = c;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    uint32_t v = __shfl_up(inc, o);
+                    if (lane >= o)
+                        inc += v;
+                }
+                const uint32_t total = __shfl(inc, 63);
+                // One row of the row machine costs about as much as 30 exact groups: a chunk whose rows keep
+                // exceeding that (dense foreground), or that has used up its share of the list, hands the rest of
+                // its rows over; a bubble's chord stays well below it.
+                hot += total > 32u;
+                if (hot >= 4u || spent + npend + total > budget) {
+                    handover = y0 + tt - 4;
+                } else {
+                    if (npend + total > K2B_PEND)
+                        flush();
+                    uint32_t pos = npend + inc - c;
+                    const uint32_t code0 = (uint32_t)(y0 + tt - 4) * ngroups + (uint32_t)lane * NDW;
+#pragma unroll
+                    for (int g = 0; g < NDW; g++)
+                        if (fmask & (1u << g))
+                            pend[pos++] = code0 + g;
+                    npend += total;
+                }
+            }
+        }
+    }
+    flush();
+    if (handover >= 0 && lane == 0)
+        units[atomicAdd(nunits, 1u)] = make_uint2((uint32_t)unit, (uint32_t)handover); // capacity = number of units
+}
+
+// one lane per listed group: D for its four pixels, straight from the definition (AnalyzerUnit.cpp:351-370)
+__global__ __launch_bounds__(256) void k2_exact_groups(const uint8_t *__restrict__ frames,
+                                                       const uint8_t *__restrict__ sigma6,
+                                                       const abub_job *__restrict__ jobs, int W, int H,
+                                                       const uint2 *__restrict__ list, const uint32_t *__restrict__ nlist,
+                                                       uint32_t listcap, uint32_t *__restrict__ hist)
+{
+    uint32_t n = *nlist;
+    if (n > listcap)
+        n = listcap;
+    const size_t P = (size_t)W * H;
+    const uint32_t ngroups = (uint32_t)W / 4;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const uint2 en = list[e];
+        const abub_job jb = jobs[en.x];
+        const int y = (int)(en.y / ngroups), x0 = (int)(en.y % ngroups) * 4;
+        const uint8_t *cur = frames + (size_t)jb.cur * P;
+        const uint8_t *ref = frames + (size_t)jb.ref * P;
+        const uint8_t *sg = sigma6 + (size_t)jb.model * P;
+        // interior groups read their 12-byte window as three aligned dwords per array and row; the two edge groups
+        // (reflected columns) take the byte path
+        const bool interior = x0 >= 4 && x0 + 8 <= W;
+        int xs[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            xs[j] = reflect101(x0 - 2 + j, W);
+        int Sp[4] = {0, 0, 0, 0}, Sn[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const size_t ro = (size_t)reflect101(y - 2 + i, H) * W;
+            int pp[8], nn[8];
+            if (interior) {
+                const uint32_t *pc = reinterpret_cast<const uint32_t *>(cur + ro + x0 - 4);
+                const uint32_t *pr = reinterpret_cast<const uint32_t *>(ref + ro + x0 - 4);
+                const uint32_t *ps = reinterpret_cast<const uint32_t *>(sg + ro + x0 - 4);
+                const uint32_t cw[3] = {pc[0], pc[1], pc[2]}, rw[3] = {pr[0], pr[1], pr[2]}, sw[3] = {ps[0], ps[1], ps[2]};
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int q = (2 + j) >> 2, sh = 8 * ((2 + j) & 3);
+                    const int c = (cw[q] >> sh) & 0xff, r = (rw[q] >> sh) & 0xff, s6 = (sw[q] >> sh) & 0xff;
+                    int a = c - r - s6, b = r - c - s6;
+                    pp[j] = a > 0 ? a : 0;
+                    nn[j] = b > 0 ? b : 0;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int c = cur[ro + xs[j]], r = ref[ro + xs[j]], s6 = sg[ro + xs[j]];
+                    int a = c - r - s6, b = r - c - s6;
+                    pp[j] = a > 0 ? a : 0;
+                    nn[j] = b > 0 ? b : 0;
+                }
+            }
+            const int wv = (i == 0 || i == 4) ? 1 : (i == 2 ? 6 : 4);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                Sp[k] += wv * (pp[k] + 4 * pp[k + 1] + 6 * pp[k + 2] + 4 * pp[k + 3] + pp[k + 4]);
+                Sn[k] += wv * (nn[k] + 4 * nn[k + 1] + 6 * nn[k + 2] + 4 * nn[k + 3] + nn[k + 4]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int a = (Sp[k] + 128) >> 8, b = (Sn[k] + 128) >> 8;
+            const int d = a > b ? a - b : b - a;
+            if (d)
+                atomicAdd(&hist[(size_t)jb.out * 256 + d], 1u);
+        }
     }
 }
 
@@ -617,6 +857,55 @@ static int pick_ndw(int W)
     return 0;
 }
 
+// Per-stream scratch of the bound-and-verify pass (grow-only; launches on one stream are ordered, launches on
+// different streams get different buffers).  Growth frees the old buffer only after the stream has drained.
+struct K2ScratchBuf {
+    void *p = nullptr;
+    size_t n = 0;
+};
+static std::mutex g_scratchMu;
+static std::map<std::pair<int, hipStream_t>, K2ScratchBuf> g_scratch;
+
+static void *k2_scratch(hipStream_t st, size_t bytes)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratchMu);
+    K2ScratchBuf &b = g_scratch[std::make_pair(dev, st)];
+    if (b.n < bytes) {
+        if (b.p) {
+            (void)hipStreamSynchronize(st);
+            (void)hipFree(b.p);
+            b.p = nullptr;
+            b.n = 0;
+        }
+        const size_t want = bytes + bytes / 4;
+        if (hipMalloc(&b.p, want) != hipSuccess) {
+            b.p = nullptr;
+            return nullptr;
+        }
+        b.n = want;
+    }
+    return b.p;
+}
+
+extern "C" int abub_scratch_release(void *stream)
+{
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(g_scratchMu);
+    auto it = g_scratch.find(std::make_pair(dev, st));
+    if (it == g_scratch.end())
+        return ABUB_OK;
+    (void)hipStreamSynchronize(st);
+    if (it->second.p)
+        (void)hipFree(it->second.p);
+    g_scratch.erase(it);
+    return ABUB_OK;
+}
+
 struct CompactArgs {
     const int32_t *cthr;
     uint32_t *pairs;
@@ -633,7 +922,7 @@ static void launch_k2_rows_pf(const uint8_t *frames, const uint8_t *sigma6, cons
     dim3 grid((unsigned)njobs * nchunks), block(64);
 #define K2_LAUNCH(ST, CO)                                                                                        \
     hipLaunchKernelGGL((k2_rows<NDW, ST, PF, CO>), grid, block, 0, st, frames, sigma6, jobs, W, H, R, nchunks, \
-                       hist, diff, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base)
+                       hist, diff, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base, nullptr, nullptr)
     if (ca.cthr) {
         if (diff)
             K2_LAUNCH(true, true);
@@ -649,10 +938,43 @@ static void launch_k2_rows_pf(const uint8_t *frames, const uint8_t *sigma6, cons
 }
 
 template <int NDW>
-static void launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
+static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
                            int njobs, int W, int H, int R, int nchunks, uint32_t *hist, uint8_t *diff,
                            const CompactArgs &ca, hipStream_t st)
 {
+    static int bound = -1;
+    if (bound < 0) {
+        const char *e = getenv("ABUB_K2_BOUND"); // 0: always the full row machine (k2_rows)
+        bound = e ? atoi(e) : 1;
+    }
+    if (bound && !diff && !ca.cthr) {
+        // trigger-only: bound-and-verify (see k2_bound_scan)
+        const size_t nunits = (size_t)njobs * nchunks;
+        // every chunk may list up to `budget` suspicious groups (then it hands its remaining rows to the row machine),
+        // so the list can never overflow; 64 M entries = 512 MB at most
+        size_t budget = 512;
+        if (nunits * budget > ((size_t)64 << 20))
+            budget = ((size_t)64 << 20) / nunits;
+        const size_t cap = nunits * budget;
+        const size_t unitBytes = (nunits * sizeof(uint2) + 255) & ~(size_t)255;
+        const size_t bytes = 256 + unitBytes + cap * sizeof(uint2) + 256;
+        uint8_t *scr = (uint8_t *)k2_scratch(st, bytes);
+        if (!scr)
+            return set_err(ABUB_E_HIP, "abub_diff_hist_dev: scratch allocation failed");
+        uint32_t *counters = (uint32_t *)scr; // [0] = list entries, [1] = handed-over units
+        uint2 *units = (uint2 *)(scr + 256);
+        uint2 *list = (uint2 *)(scr + 256 + unitBytes);
+        HIPCHK(hipMemsetAsync(counters, 0, 2 * sizeof(uint32_t), st));
+        hipLaunchKernelGGL((k2_bound_scan<NDW>), dim3((unsigned)nunits), dim3(64), 0, st, frames, sigma6, jobs, W, H, R,
+                           nchunks, list, counters, (uint32_t)budget, units, counters + 1);
+        hipLaunchKernelGGL(k2_exact_groups, dim3(1024), dim3(256), 0, st, frames, sigma6, jobs, W, H, list, counters,
+                           (uint32_t)cap, hist);
+        const unsigned g3 = (unsigned)(nunits < 2048 ? nunits : 2048);
+        hipLaunchKernelGGL((k2_rows<NDW, false, 1, false>), dim3(g3), dim3(64), 0, st, frames, sigma6, jobs, W, H, R,
+                           nchunks, hist, (uint8_t *)nullptr, (const int32_t *)nullptr, (uint32_t *)nullptr, 0u,
+                           (uint32_t *)nullptr, 0u, units, counters + 1);
+        return ABUB_OK;
+    }
     // prefetch depth 1 won on MI355X: depth 2/3 rings cost a wave of occupancy and ran 10-17 % slower
     // (measured in round 1, see DESIGN.md "Tuning log")
     static int pf = -1;
@@ -664,6 +986,7 @@ static void launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const a
         launch_k2_rows_pf<NDW, 2>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st);
     else
         launch_k2_rows_pf<NDW, 1>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st);
+    return ABUB_OK;
 }
 
 static int diff_hist_impl(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs, int njobs,
@@ -693,16 +1016,19 @@ static int diff_hist_impl(const uint8_t *frames, const uint8_t *sigma6, const ab
                 R = 16;
         }
         int nchunks = (H + R - 1) / R;
+        int rc = ABUB_OK;
         switch (ndw) {
-        case 1: launch_k2_rows<1>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
-        case 2: launch_k2_rows<2>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
-        case 3: launch_k2_rows<3>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
-        case 4: launch_k2_rows<4>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
-        case 5: launch_k2_rows<5>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
-        case 6: launch_k2_rows<6>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
-        case 7: launch_k2_rows<7>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
-        default: launch_k2_rows<8>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        case 1: rc = launch_k2_rows<1>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        case 2: rc = launch_k2_rows<2>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        case 3: rc = launch_k2_rows<3>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        case 4: rc = launch_k2_rows<4>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        case 5: rc = launch_k2_rows<5>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        case 6: rc = launch_k2_rows<6>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        case 7: rc = launch_k2_rows<7>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        default: rc = launch_k2_rows<8>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
         }
+        if (rc != ABUB_OK)
+            return rc;
     } else {
         if (ca.cthr)
             return set_err(ABUB_E_INVALID, "fused compaction needs the fast path (W % 4 == 0, W <= 2048)");

@@ -388,15 +388,19 @@ public:
     {
         (void)hipSetDevice(device);
         for (Group &G : groups) {
-            if (G.stream)
+            if (G.stream) {
+                (void)abub_scratch_release(G.stream);
                 (void)hipStreamDestroy(G.stream);
+            }
             if (G.stage1Done)
                 (void)hipEventDestroy(G.stage1Done);
             if (G.kernelsDone)
                 (void)hipEventDestroy(G.kernelsDone);
         }
-        if (stage1Stream)
+        if (stage1Stream) {
+            (void)abub_scratch_release(stage1Stream); // the trigger search's work list lives in library scratch
             (void)hipStreamDestroy(stage1Stream);
+        }
         if (copyStream)
             (void)hipStreamDestroy(copyStream);
         for (auto &e : copied)

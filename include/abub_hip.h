@@ -109,6 +109,11 @@ int abub_fg_compact_dev(const uint8_t *img, int nimg, int W, int H, const int32_
  * known before the launch, the final Otsu cut is applied to the listed values on the host.
  * Fast path only (abub_fast_path(W) != 0). */
 int abub_fast_path(int W);
+
+/* The trigger-only form of abub_diff_hist_dev (diff == NULL) keeps a work list in device scratch memory that the
+ * library owns, one buffer per (device, stream), grown on demand.  Call this before destroying a stream that was
+ * used for such launches (or at any quiet moment) to give its buffer back; it waits for the stream to drain. */
+int abub_scratch_release(void *stream);
 int abub_diff_hist_compact_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs, int njobs,
                                int W, int H, uint32_t *hist, uint8_t *diff, const int32_t *cthr,
                                uint32_t *pairs, uint32_t cap, uint32_t *count, uint32_t slot_base,

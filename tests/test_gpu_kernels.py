@@ -69,6 +69,42 @@ def test_k2_extreme_values(oracle):
     hist, diff = hip.diff_hist(f_d, s6, hip.make_jobs(jobs, DEV), W, H, store=True)
     assert np.array_equal(diff.cpu().numpy(), Dref)
     assert np.array_equal(hist.cpu().numpy().astype(np.uint32), href)
+    hist, _ = hip.diff_hist(f_d, s6, hip.make_jobs(jobs, DEV), W, H, store=False)  # trigger-only kernel
+    assert np.array_equal(hist.cpu().numpy().astype(np.uint32), href)
+
+
+@pytest.mark.parametrize("H,W,R", [(96, 1280, 0), (70, 1680, 16), (40, 256, 8), (33, 2048, 0), (64, 100, 16)])
+def test_k2_trigger_only_bound_and_verify(oracle, H, W, R):
+    """The trigger-only kernel proves most rows zero from a bound and recomputes the rest exactly.  Inputs that sit
+    on both sides of the decision: isolated supra-threshold pixels of value 1..5 (36*3 = 108 < 128 <= 36*4), pairs and
+    small clusters whose sums cross 128 only together, the same at the image edges and corners (reflected taps),
+    and at chunk boundaries; sigma = 0 so that X = |cur - ref| exactly."""
+    rs = np.random.RandomState(W * 31 + H)
+    n = 7
+    ref = rs.randint(20, 200, (H, W)).astype(np.int64)
+    frames = np.repeat(ref[None], n, 0)
+    for f in range(1, n):
+        k = rs.randint(40, 400)
+        ys, xs = rs.randint(0, H, k), rs.randint(0, W, k)
+        frames[f, ys, xs] += rs.choice([-1, 1], k) * rs.randint(1, 6, k)
+        for _ in range(12):  # tight clusters: two / three small values next to each other
+            y, x = rs.randint(0, H - 1), rs.randint(0, W - 2)
+            frames[f, y, x] += rs.randint(1, 4)
+            frames[f, y + rs.randint(0, 2), x + rs.randint(0, 3)] += rs.randint(1, 4)
+        for (y, x) in [(0, 0), (0, 1), (1, 0), (H - 1, W - 1), (H - 2, W - 1), (H - 1, W - 2), (0, W - 1), (H - 1, 0)]:
+            frames[f, y, x] += rs.randint(-4, 5)
+        if R:
+            for y in range(R - 2, H, R):  # around chunk boundaries
+                frames[f, min(y + rs.randint(0, 4), H - 1), rs.randint(0, W)] += rs.randint(3, 6)
+    frames = np.clip(frames, 0, 255).astype(np.uint8)
+    sigma = np.zeros((1, H, W), np.uint8)
+    jobs = [(i, 0, 0, i - 1) for i in range(1, n)]
+    _, href = oracle_hists(oracle, frames, sigma, jobs)
+    assert 0 < (href[:, 1:].sum(1) > 0).sum()  # some frames show something, most pixels show nothing
+    f_d = torch.from_numpy(frames).to(DEV)
+    s6 = hip.sigma6(torch.from_numpy(sigma).to(DEV))
+    hist, _ = hip.diff_hist(f_d, s6, hip.make_jobs(jobs, DEV), W, H, store=False, rows_per_chunk=R)
+    assert np.array_equal(hist.cpu().numpy().astype(np.uint32), href)
 
 
 def test_k2_stack_jobs_and_synthetic_event(oracle):
@@ -240,3 +276,30 @@ def test_fused_compaction_lists(oracle):
     assert total == n and n > 100
     assert np.array_equal(hist2.cpu().numpy().astype(np.uint32), np.stack([oracle.hist256(imgs[0]), oracle.hist256(imgs[1])]))
     assert np.array_equal(hist3.cpu().numpy().astype(np.uint32), np.stack([oracle.hist256(imgs[2]), oracle.hist256(imgs[3])]))
+
+
+@pytest.mark.parametrize("W,H", [(1280, 1024), (1680, 1050)])
+def test_k2_trigger_only_equals_store_mode_full_size(W, H):
+    """Size-independent cross-check at BASELINE's frame sizes: the trigger-only pass (bound scan + exact groups +
+    hand-over) and the store-mode pass (full row machine) are different code paths and must give the same
+    histograms, which must also be the histograms of the stored D.  The stack mixes quiet frames, growing bubbles
+    (up to ~45 px radius), a flicker frame, a frame that differs everywhere (dense: the scan hands whole chunks over)
+    and a frame with a dense band in the middle of a chunk (partial hand-over)."""
+    F = 24
+    spec = synth.EventSpec(F, t0=6, bubbles=[(W // 3, H // 2, 40), (2 * W // 3, H // 3, -40)], flicker=4)
+    fr = synth.render_event(W, H, spec, 77, 0, xp="torch", device=DEV)
+    fr[20] = torch.clamp(fr[20].to(torch.int16) + 25, 0, 255).to(torch.uint8)
+    band = fr[22, 200:260].to(torch.int16)
+    band[:, ::3] += 30
+    fr[22, 200:260] = torch.clamp(band, 0, 255).to(torch.uint8)
+    sg = torch.ones((1, H, W), dtype=torch.uint8, device=DEV)
+    sg[0, :, W // 2:] = 2
+    s6 = hip.sigma6(sg)
+    jobs = hip.stack_jobs(1, F, 1, F - 1, 2, 1, DEV)
+    h_trig, _ = hip.diff_hist(fr, s6, jobs, W, H, store=False)
+    h_store, D = hip.diff_hist(fr, s6, jobs, W, H, store=True)
+    torch.cuda.synchronize()
+    assert torch.equal(h_trig, h_store)
+    for k in (0, 5, 12, 19, 21, 22):
+        assert torch.equal(torch.bincount(D[k].flatten().to(torch.int64), minlength=256).to(h_store.dtype), h_store[k])
+    assert int(h_store[19, 1:].sum()) > W * H // 2  # the dense frame really is dense
