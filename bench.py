@@ -215,7 +215,8 @@ def main():
             "pcie_inclusive": pcie,
         },
         "roofline": {
-            "kernel": "k2_rows<5,false,1> (fused ProcessFrame + 256-bin histogram, trigger-only mode: 3*W*H B/job)",
+            "kernel": "K2 trigger-only pass = k2_bound_scan<5> (dominant) + k2_exact_groups + k2_rows<5> on handed-over "
+                      "rows + k_hist_bin0, timed together: fused ProcessFrame + 256-bin histogram, 3*W*H B/job",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
             "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,

@@ -11,19 +11,26 @@ import sys
 
 def main(d, out):
     micro = json.loads(open(os.path.join(d, "micro.json")).read().strip().splitlines()[-1])
-    c = {}
+    # one microbench launch = one dispatch of each K2 kernel involved (trigger-only: bound scan + exact groups +
+    # row machine on the handed-over rows; store mode: the row machine alone): mean per dispatch and kernel, then
+    # summed over the kernels
+    per = {}
     meta = {}
     for f in glob.glob(os.path.join(d, "pmc_*.csv")):
         for r in csv.DictReader(open(f)):
-            c.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-            meta = {k: r.get(k) for k in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Kernel_Name")}
-    m = {k: sum(v) / len(v) for k, v in c.items()}
+            kn = r["Kernel_Name"].split("(")[0]
+            per.setdefault(r["Counter_Name"], {}).setdefault(kn, []).append(float(r["Counter_Value"]))
+            if kn not in meta:
+                meta[kn] = {k: r.get(k) for k in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size")}
+    m = {cn: sum(sum(v) / len(v) for v in kd.values()) for cn, kd in per.items()}
+    by_kernel = {cn: {kn: sum(v) / len(v) for kn, v in kd.items()} for cn, kd in per.items()
+                 if cn in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES")}
     jobs = micro["frames"]
     fetch = m.get("FETCH_SIZE", 0) * 1024 * 2
     write = m.get("WRITE_SIZE", 0) * 1024
     P = micro["W"] * micro["H"]
     res = {
-        "micro": micro, "kernel": meta,
+        "micro": micro, "kernels": meta,
         "hbm_read_bytes_per_launch": fetch, "hbm_write_bytes_per_launch": write,
         "hbm_bytes_per_job": (fetch + write) / jobs, "hbm_bytes_per_job_over_WH": (fetch + write) / jobs / P,
         "algorithmic_bytes_per_job": (4 if micro["store"] else 3) * P,
@@ -31,7 +38,7 @@ def main(d, out):
         "valu_insts_per_pixel_lane": m.get("SQ_INSTS_VALU", 0) * 64 / (jobs * P),
         "wave_cycles_share": {k: m.get(k, 0) / max(1.0, m.get("SQ_WAVE_CYCLES", 1)) for k in
                               ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU")},
-        "counters_mean": m,
+        "counters_mean": m, "counters_by_kernel": by_kernel,
         "corrections": "FETCH_SIZE KiB x2 (gfx950 wide streaming reads), WRITE_SIZE KiB x1; separate --pmc passes",
     }
     json.dump(res, open(out, "w"), indent=1)
