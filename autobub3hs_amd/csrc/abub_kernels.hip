@@ -579,6 +579,90 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER
 #define K2B_PEND 512 /* >= the groups of one row (W/4 <= 512) */
 
 template <int NDW>
+struct K2BoundJob { // per-job state of the bound recurrence and of its suspect list (all wave-uniform but b*/Mprev)
+    uint32_t b0[NDW], b1[NDW], b2[NDW], Mprev[NDW];
+    uint32_t npend, spent, hot, jidx;
+    int handover; // < 0: scanning; >= 0: first output row left to the row machine (or "nothing to do")
+};
+
+template <int NDW>
+__device__ __forceinline__ void k2b_flush(K2BoundJob<NDW> &J, uint32_t *pend, uint2 *__restrict__ list,
+                                          uint32_t *__restrict__ nlist, int lane)
+{
+    if (J.npend == 0)
+        return;
+    __syncthreads(); // (one wave: orders the LDS writes before the reads below)
+    uint32_t base = 0;
+    if (lane == 0)
+        base = atomicAdd(nlist, J.npend);
+    base = __shfl(base, 0);
+    for (uint32_t i = lane; i < J.npend; i += 64)
+        list[base + i] = make_uint2(J.jidx, pend[i]);
+    __syncthreads();
+    J.spent += J.npend;
+    J.npend = 0;
+}
+
+// one input row of one job: group masses m[] -> bound of output row y; suspects go to the job's list
+template <int NDW>
+__device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const uint32_t (&m)[NDW], bool emit, int y, bool active,
+                                        bool first_lane, bool last_lane, int lane, uint32_t ngroups, uint32_t budget,
+                                        uint32_t *pend, uint2 *__restrict__ list, uint32_t *__restrict__ nlist)
+{
+    uint32_t mL = __builtin_amdgcn_update_dpp(0u, m[NDW - 1], DPP_WAVE_SHR1, 0xf, 0xf, false);
+    uint32_t mR = __builtin_amdgcn_update_dpp(0u, m[0], DPP_WAVE_SHL1, 0xf, 0xf, false);
+    mL = first_lane ? m[0] : mL;
+    mR = last_lane ? m[NDW - 1] : mR;
+    uint32_t B[NDW];
+    uint32_t worst = 0;
+#pragma unroll
+    for (int g = 0; g < NDW; g++) {
+        const uint32_t M = (g ? m[g - 1] : mL) + m[g] + (g + 1 < NDW ? m[g + 1] : mR);
+        B[g] = J.b0[g] + M;
+        const uint32_t M4 = M << 2;
+        J.b0[g] = J.b1[g] + M4;
+        J.b1[g] = pk_madk<6>(M, J.b2[g]);
+        J.b2[g] = J.Mprev[g] + M4;
+        J.Mprev[g] = M;
+        u16x2 w = __builtin_bit_cast(u16x2, worst), bb = __builtin_bit_cast(u16x2, B[g]);
+        worst = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(w, bb));
+    }
+    const bool unsure = active && ((worst & 0xffffu) + (worst >> 16)) > 21u; // 6 * (lo + hi) < 128 <=> lo + hi <= 21
+    if (!(emit && __builtin_amdgcn_ballot_w64(unsure)))
+        return;
+    uint32_t fmask = 0;
+    if (active) {
+#pragma unroll
+        for (int g = 0; g < NDW; g++)
+            if ((B[g] & 0xffffu) + (B[g] >> 16) > 21u)
+                fmask |= 1u << g;
+    }
+    const uint32_t c = __builtin_popcount(fmask);
+    uint32_t inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t v = __shfl_up(inc, o);
+        if (lane >= o)
+            inc += v;
+    }
+    const uint32_t total = __shfl(inc, 63);
+    J.hot += total > 32u; // (same hand-over policy as k2_bound_scan)
+    if (J.hot >= 4u || J.spent + J.npend + total > budget) {
+        J.handover = y;
+        return;
+    }
+    if (J.npend + total > K2B_PEND)
+        k2b_flush<NDW>(J, pend, list, nlist, lane);
+    uint32_t pos = J.npend + inc - c;
+    const uint32_t code0 = (uint32_t)y * ngroups + (uint32_t)lane * NDW;
+#pragma unroll
+    for (int g = 0; g < NDW; g++)
+        if (fmask & (1u << g))
+            pend[pos++] = code0 + g;
+    J.npend += total;
+}
+
+template <int NDW>
 __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ frames,
                                                     const uint8_t *__restrict__ sigma6,
                                                     const abub_job *__restrict__ jobs, int W, int H,
@@ -609,103 +693,194 @@ __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ 
     const int T = y1 - y0 + 4; // input rows y0-2 .. y1+1 (reflected); step tt bounds output row y0+tt-4
     const uint32_t ngroups = (uint32_t)W / 4;
 
-    uint32_t b0[NDW], b1[NDW], b2[NDW], Mprev[NDW];
+    K2BoundJob<NDW> J;
 #pragma unroll
     for (int g = 0; g < NDW; g++)
-        b0[g] = b1[g] = b2[g] = Mprev[g] = 0;
-    uint32_t npend = 0, spent = 0, hot = 0; // wave-uniform: pending in LDS, already flushed, rows with many suspects
-    int handover = -1;                      // first output row left to the row machine
-    // The list has room for `budget` entries per chunk, so a reservation can never overflow it.
-    auto flush = [&]() {
-        if (npend == 0)
-            return;
-        __syncthreads(); // (one wave: orders the LDS writes before the reads below)
-        uint32_t base = 0;
-        if (lane == 0)
-            base = atomicAdd(nlist, npend);
-        base = __shfl(base, 0);
-        for (uint32_t i = lane; i < npend; i += 64)
-            list[base + i] = make_uint2((uint32_t)job, pend[i]);
-        __syncthreads();
-        spent += npend;
-        npend = 0;
-    };
+        J.b0[g] = J.b1[g] = J.b2[g] = J.Mprev[g] = 0;
+    J.npend = J.spent = J.hot = 0;
+    J.jidx = (uint32_t)job;
+    J.handover = -1;
 
     RowIn<NDW> ring[2];
     k2_load_row<NDW>(ring[0], cur, ref, sg, reflect101(y0 - 2, H), W, xoff);
     const int Tpad = (T + 1) & ~1;
-    for (int t = 0; t < Tpad && handover < 0; t += 2) {
+    for (int t = 0; t < Tpad && J.handover < 0; t += 2) {
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int tt = t + u;
             int tn = tt + 1 < T ? tt + 1 : T - 1;
             k2_load_row<NDW>(ring[u ^ 1], cur, ref, sg, reflect101(y0 - 2 + tn, H), W, xoff);
-            uint32_t Xp[NP], Xn[NP];
-            k2_planes<NDW>(ring[u], Xp, Xn);
-            uint32_t m[NDW];
+            if (J.handover < 0) {
+                uint32_t Xp[NP], Xn[NP];
+                k2_planes<NDW>(ring[u], Xp, Xn);
+                uint32_t m[NDW];
 #pragma unroll
-            for (int g = 0; g < NDW; g++)
-                m[g] = (Xp[2 * g] + Xn[2 * g]) + (Xp[2 * g + 1] + Xn[2 * g + 1]);
-            uint32_t mL = __builtin_amdgcn_update_dpp(0u, m[NDW - 1], DPP_WAVE_SHR1, 0xf, 0xf, false);
-            uint32_t mR = __builtin_amdgcn_update_dpp(0u, m[0], DPP_WAVE_SHL1, 0xf, 0xf, false);
-            mL = first_lane ? m[0] : mL;
-            mR = last_lane ? m[NDW - 1] : mR;
-            uint32_t B[NDW];
-            uint32_t worst = 0;
-#pragma unroll
-            for (int g = 0; g < NDW; g++) {
-                const uint32_t M = (g ? m[g - 1] : mL) + m[g] + (g + 1 < NDW ? m[g + 1] : mR);
-                B[g] = b0[g] + M; // bound / 6 of output row tt-4 for the columns of group g
-                const uint32_t M4 = M << 2;
-                b0[g] = b1[g] + M4;
-                b1[g] = pk_madk<6>(M, b2[g]);
-                b2[g] = Mprev[g] + M4;
-                Mprev[g] = M;
-                u16x2 w = __builtin_bit_cast(u16x2, worst), bb = __builtin_bit_cast(u16x2, B[g]);
-                worst = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(w, bb));
-            }
-            // 6 * (lo + hi) < 128  <=>  lo + hi <= 21
-            const bool unsure = active && ((worst & 0xffffu) + (worst >> 16)) > 21u;
-            if (tt >= 4 && tt < T && handover < 0 && __builtin_amdgcn_ballot_w64(unsure)) {
-                uint32_t fmask = 0;
-                if (active) {
-#pragma unroll
-                    for (int g = 0; g < NDW; g++)
-                        if ((B[g] & 0xffffu) + (B[g] >> 16) > 21u)
-                            fmask |= 1u << g;
-                }
-                const uint32_t c = __builtin_popcount(fmask);
-                uint32_t inc = c;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    uint32_t v = __shfl_up(inc, o);
-                    if (lane >= o)
-                        inc += v;
-                }
-                const uint32_t total = __shfl(inc, 63);
-                // One row of the row machine costs about as much as 30 exact groups: a chunk whose rows keep
-                // exceeding that (dense foreground), or that has used up its share of the list, hands the rest of
-                // its rows over; a bubble's chord stays well below it.
-                hot += total > 32u;
-                if (hot >= 4u || spent + npend + total > budget) {
-                    handover = y0 + tt - 4;
-                } else {
-                    if (npend + total > K2B_PEND)
-                        flush();
-                    uint32_t pos = npend + inc - c;
-                    const uint32_t code0 = (uint32_t)(y0 + tt - 4) * ngroups + (uint32_t)lane * NDW;
-#pragma unroll
-                    for (int g = 0; g < NDW; g++)
-                        if (fmask & (1u << g))
-                            pend[pos++] = code0 + g;
-                    npend += total;
-                }
+                for (int g = 0; g < NDW; g++)
+                    m[g] = (Xp[2 * g] + Xn[2 * g]) + (Xp[2 * g + 1] + Xn[2 * g + 1]);
+                k2b_row<NDW>(J, m, tt >= 4 && tt < T, y0 + tt - 4, active, first_lane, last_lane, lane, ngroups, budget,
+                             pend, list, nlist);
             }
         }
     }
-    flush();
-    if (handover >= 0 && lane == 0)
-        units[atomicAdd(nunits, 1u)] = make_uint2((uint32_t)unit, (uint32_t)handover); // capacity = number of units
+    k2b_flush<NDW>(J, pend, list, nlist, lane);
+    if (J.handover >= 0 && lane == 0)
+        units[atomicAdd(nunits, 1u)] = make_uint2((uint32_t)unit, (uint32_t)J.handover); // capacity = number of units
+}
+
+// ------------------------------------------------------------------------------------------------
+// k2_bound_chain: the bound scan for job lists with the trigger search's structure -- blocks of `L` consecutive jobs
+// in which job q takes the cur frame of job q - S as its ref (FindTriggerFrame: S = 2, or 1 for small training sets).
+// One wave serves up to K jobs of one such chain for one chunk: every frame row is loaded once and used as the cur
+// row of one job and the ref row of the next, sigma6 once for all -- (K + 2) / K row loads per job instead of 3.
+// The scan is bound by the number of row requests the memory system takes (tools/k2_readonly.cpp: 0.30 us per job
+// with 3 streams per job, 0.24 with K = 2, 0.22 with K = 4), not by bytes from HBM.
+// The chain property is only a hint: the wave checks it on the job records and hands units it cannot chain to the row
+// machine, so any job list gives the same histograms as k2_bound_scan / k2_rows.
+// ------------------------------------------------------------------------------------------------
+template <int NDW, int K>
+__global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__ frames,
+                                                     const uint8_t *__restrict__ sigma6,
+                                                     const abub_job *__restrict__ jobs, int L, int S, int nslot, int W,
+                                                     int H, int rows_per_chunk, int nchunks, uint2 *__restrict__ list,
+                                                     uint32_t *__restrict__ nlist, uint32_t budget,
+                                                     uint2 *__restrict__ units, uint32_t *__restrict__ nunits)
+{
+    __shared__ uint32_t pend[K][K2B_PEND];
+    const int lane = threadIdx.x;
+    const int chunk = blockIdx.x % nchunks;
+    const int bs = blockIdx.x / nchunks; // (block of L jobs, slot)
+    const int blk = bs / nslot;
+    int slot = bs - blk * nslot;
+    // slot -> (residue r, segment q of that residue's chain)
+    int r = 0, nr = 0;
+    for (r = 0; r < S; r++) {
+        nr = (L - r + S - 1) / S; // jobs of residue r in the block
+        const int ns = (nr + K - 1) / K;
+        if (slot < ns)
+            break;
+        slot -= ns;
+    }
+    const int k = nr - slot * K < K ? nr - slot * K : K; // jobs of this wave (>= 1)
+    K2BoundJob<NDW> J[K];
+    abub_job jb[K];
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+        const int tc = t < k ? t : k - 1;
+        J[t].jidx = (uint32_t)(blk * L + r + S * (slot * K + tc));
+        jb[t] = jobs[J[t].jidx];
+    }
+    const int y0 = chunk * rows_per_chunk;
+    bool chained = true;
+#pragma unroll
+    for (int t = 1; t < K; t++)
+        if (t < k && (jb[t].ref != jb[t - 1].cur || jb[t].model != jb[0].model))
+            chained = false;
+    if (!chained) { // not the structure promised: every unit goes to the row machine whole
+        if (lane < k) {
+            uint32_t j = J[0].jidx;
+#pragma unroll
+            for (int t = 1; t < K; t++)
+                j = lane == t ? J[t].jidx : j;
+            units[atomicAdd(nunits, 1u)] = make_uint2(j * (uint32_t)nchunks + (uint32_t)chunk, (uint32_t)y0);
+        }
+        return;
+    }
+    const size_t P = (size_t)W * H;
+    const uint8_t *fp[K + 1];
+    fp[0] = frames + (size_t)jb[0].ref * P;
+#pragma unroll
+    for (int t = 0; t < K; t++)
+        fp[t + 1] = frames + (size_t)jb[t].cur * P;
+    const uint8_t *sg = sigma6 + (size_t)jb[0].model * P;
+    const int nl = W / (4 * NDW);
+    const bool active = lane < nl;
+    const bool first_lane = lane == 0;
+    const bool last_lane = lane == nl - 1;
+    const int xoff = active ? lane * 4 * NDW : 0;
+    int y1 = y0 + rows_per_chunk;
+    if (y1 > H)
+        y1 = H;
+    const int T = y1 - y0 + 4;
+    const uint32_t ngroups = (uint32_t)W / 4;
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+#pragma unroll
+        for (int g = 0; g < NDW; g++)
+            J[t].b0[g] = J[t].b1[g] = J[t].b2[g] = J[t].Mprev[g] = 0;
+        J[t].npend = J[t].spent = J[t].hot = 0;
+        J[t].handover = t < k ? -1 : 0x7fffffff; // (jobs beyond k do nothing and report nothing)
+    }
+
+    uint32_t raw[2][K + 2][NDW]; // [K + 1] = sigma6
+#define K2C_LOAD(SL, Y)                                                                       \
+    {                                                                                         \
+        const size_t o_ = (size_t)(Y) * W + xoff;                                             \
+        _Pragma("unroll") for (int f = 0; f <= K; f++)                                        \
+        {                                                                                     \
+            const uint32_t *pf_ = reinterpret_cast<const uint32_t *>(fp[f] + o_);             \
+            _Pragma("unroll") for (int d = 0; d < NDW; d++) raw[SL][f][d] = pf_[d];           \
+        }                                                                                     \
+        const uint32_t *ps_ = reinterpret_cast<const uint32_t *>(sg + o_);                    \
+        _Pragma("unroll") for (int d = 0; d < NDW; d++) raw[SL][K + 1][d] = ps_[d];           \
+    }
+    K2C_LOAD(0, reflect101(y0 - 2, H));
+    const int Tpad = (T + 1) & ~1;
+    for (int t0 = 0; t0 < Tpad; t0 += 2) {
+        bool all_done = true;
+#pragma unroll
+        for (int t = 0; t < K; t++)
+            all_done = all_done && J[t].handover >= 0;
+        if (all_done)
+            break;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int tt = t0 + u;
+            const int tn = tt + 1 < T ? tt + 1 : T - 1;
+            K2C_LOAD(u ^ 1, reflect101(y0 - 2 + tn, H));
+            uint32_t sw[2 * NDW], pw[2 * NDW];
+#pragma unroll
+            for (int d = 0; d < NDW; d++) {
+                sw[2 * d] = widen_lo(raw[u][K + 1][d]);
+                sw[2 * d + 1] = widen_hi(raw[u][K + 1][d]);
+                pw[2 * d] = widen_lo(raw[u][0][d]);
+                pw[2 * d + 1] = widen_hi(raw[u][0][d]);
+            }
+#pragma unroll
+            for (int t = 0; t < K; t++) {
+                uint32_t cw[2 * NDW];
+#pragma unroll
+                for (int d = 0; d < NDW; d++) {
+                    cw[2 * d] = widen_lo(raw[u][t + 1][d]);
+                    cw[2 * d + 1] = widen_hi(raw[u][t + 1][d]);
+                }
+                if (J[t].handover < 0) {
+                    uint32_t m[NDW];
+#pragma unroll
+                    for (int g = 0; g < NDW; g++) {
+                        const uint32_t c0 = cw[2 * g], c1 = cw[2 * g + 1], r0 = pw[2 * g], r1 = pw[2 * g + 1];
+                        const uint32_t s0 = sw[2 * g], s1 = sw[2 * g + 1];
+                        m[g] = (pk_subsat(c0, r0 + s0) + pk_subsat(r0, c0 + s0)) +
+                               (pk_subsat(c1, r1 + s1) + pk_subsat(r1, c1 + s1));
+                    }
+                    k2b_row<NDW>(J[t], m, tt >= 4 && tt < T, y0 + tt - 4, active, first_lane, last_lane, lane, ngroups,
+                                 budget, pend[t], list, nlist);
+                }
+#pragma unroll
+                for (int j = 0; j < 2 * NDW; j++)
+                    pw[j] = cw[j];
+            }
+        }
+    }
+#undef K2C_LOAD
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+        if (t < k) {
+            k2b_flush<NDW>(J[t], pend[t], list, nlist, lane);
+            if (J[t].handover >= 0 && lane == 0)
+                units[atomicAdd(nunits, 1u)] =
+                    make_uint2(J[t].jidx * (uint32_t)nchunks + (uint32_t)chunk, (uint32_t)J[t].handover);
+        }
+    }
 }
 
 // one lane per listed group: D for its four pixels, straight from the definition (AnalyzerUnit.cpp:351-370)
@@ -912,6 +1087,7 @@ struct CompactArgs {
     uint32_t cap;
     uint32_t *count;
     uint32_t slot_base; // added to job.out in the list entries (several launches share one list)
+    int chain_len = 0, chain_stride = 0; // trigger-only hint: blocks of chain_len jobs, job q refs the cur of job q - stride
 };
 
 template <int NDW, int PF>
@@ -965,8 +1141,34 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
         uint2 *units = (uint2 *)(scr + 256);
         uint2 *list = (uint2 *)(scr + 256 + unitBytes);
         HIPCHK(hipMemsetAsync(counters, 0, 2 * sizeof(uint32_t), st));
-        hipLaunchKernelGGL((k2_bound_scan<NDW>), dim3((unsigned)nunits), dim3(64), 0, st, frames, sigma6, jobs, W, H, R,
-                           nchunks, list, counters, (uint32_t)budget, units, counters + 1);
+        static int chainK = -1;
+        if (chainK < 0) {
+            const char *e = getenv("ABUB_K2_CHAIN"); // jobs per wave in the chained scan (1..4; 0 = never chain)
+            chainK = e ? atoi(e) : 2;
+        }
+        const int L = ca.chain_len, S = ca.chain_stride;
+        if (chainK > 0 && L > 0 && S > 0 && S <= 8 && njobs % L == 0) {
+            const int Kc = chainK > 4 ? 4 : chainK;
+            int nslot = 0;
+            for (int r = 0; r < S; r++) {
+                const int nr = (L - r + S - 1) / S;
+                nslot += nr > 0 ? (nr + Kc - 1) / Kc : 0;
+            }
+            const dim3 grid((unsigned)((size_t)(njobs / L) * nslot * nchunks));
+#define K2C_LAUNCH(KK)                                                                                              \
+    hipLaunchKernelGGL((k2_bound_chain<NDW, KK>), grid, dim3(64), 0, st, frames, sigma6, jobs, L, S, nslot, W, H, R, \
+                       nchunks, list, counters, (uint32_t)budget, units, counters + 1)
+            switch (Kc) {
+            case 1: K2C_LAUNCH(1); break;
+            case 2: K2C_LAUNCH(2); break;
+            case 3: K2C_LAUNCH(3); break;
+            default: K2C_LAUNCH(4); break;
+            }
+#undef K2C_LAUNCH
+        } else {
+            hipLaunchKernelGGL((k2_bound_scan<NDW>), dim3((unsigned)nunits), dim3(64), 0, st, frames, sigma6, jobs, W, H, R,
+                               nchunks, list, counters, (uint32_t)budget, units, counters + 1);
+        }
         hipLaunchKernelGGL(k2_exact_groups, dim3(1024), dim3(256), 0, st, frames, sigma6, jobs, W, H, list, counters,
                            (uint32_t)cap, hist);
         const unsigned g3 = (unsigned)(nunits < 2048 ? nunits : 2048);
@@ -1051,6 +1253,18 @@ extern "C" int abub_diff_hist_dev(const uint8_t *frames, const uint8_t *sigma6, 
 {
     CompactArgs ca = {nullptr, nullptr, 0, nullptr, 0};
     return diff_hist_impl(frames, sigma6, jobs, njobs, W, H, hist, diff, rows_per_chunk, ca, stream);
+}
+
+extern "C" int abub_diff_hist_chained_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
+                                          int njobs, int W, int H, uint32_t *hist, int chain_len, int chain_stride,
+                                          void *stream)
+{
+    if (chain_len < 0 || chain_stride < 0)
+        return set_err(ABUB_E_INVALID, "abub_diff_hist_chained_dev: bad arguments");
+    CompactArgs ca = {nullptr, nullptr, 0, nullptr, 0};
+    ca.chain_len = chain_len;
+    ca.chain_stride = chain_stride;
+    return diff_hist_impl(frames, sigma6, jobs, njobs, W, H, hist, nullptr, 0, ca, stream);
 }
 
 extern "C" int abub_fast_path(int W) { return pick_ndw(W) != 0; }

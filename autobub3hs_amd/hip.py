@@ -42,14 +42,21 @@ def make_jobs(rows, device):
     return torch.tensor(list(rows), dtype=torch.int64).to(torch.int32).reshape(-1, 4).to(device)
 
 
-def diff_hist(frames, sigma6_, jobs, W, H, store=False, rows_per_chunk=0, hist=None, diff=None):
-    """K2. frames: u8 [..,H,W]; sigma6_: u8 [nmodels,H,W]; jobs: int32 [n,4] -> (hist [n,256] i32, diff|None)."""
+def diff_hist(frames, sigma6_, jobs, W, H, store=False, rows_per_chunk=0, hist=None, diff=None, chain=None):
+    """K2. frames: u8 [..,H,W]; sigma6_: u8 [nmodels,H,W]; jobs: int32 [n,4] -> (hist [n,256] i32, diff|None).
+    chain=(chain_len, chain_stride): trigger-only form with the stack-structure hint (abub_diff_hist_chained_dev)."""
     _need_cuda(frames, sigma6_, jobs)
     n = jobs.shape[0]
     if hist is None:
         hist = torch.empty((n, 256), dtype=torch.int32, device=frames.device)
     if store and diff is None:
         diff = torch.empty((n, H, W), dtype=torch.uint8, device=frames.device)
+    if chain is not None:
+        assert not store and rows_per_chunk == 0
+        _lib.check(_lib.lib().abub_diff_hist_chained_dev(_ptr(frames), _ptr(sigma6_), _ptr(jobs), n, W, H, _ptr(hist),
+                                                         int(chain[0]), int(chain[1]), _stream()),
+                   "abub_diff_hist_chained_dev")
+        return hist, None
     _lib.check(_lib.lib().abub_diff_hist_dev(_ptr(frames), _ptr(sigma6_), _ptr(jobs), n, W, H, _ptr(hist),
                                              _ptr(diff) if store else None, rows_per_chunk, _stream()),
                "abub_diff_hist_dev")

@@ -272,6 +272,7 @@ public:
     std::vector<Group> groups;
     std::unique_ptr<WorkerPool> pool;
     hipStream_t stage1Stream = nullptr; // all trigger-search launches, in group order (see run())
+    int chainStride = 0;                // FindTriggerFrame's frame offset when every camera shares it, else 0
     bool ordered = true;                // localisation kernels queue on stage1Stream too (see batchImages())
     std::vector<void *> devAllocs, hostAllocs;
     std::mutex allocMu;
@@ -320,6 +321,10 @@ public:
         if (ngroups > S)
             ngroups = S;
         const int K = NumFramesBubbleTrack + 1;
+        chainStride = tss[0] < 6 ? 1 : 2;
+        for (int c = 1; c < C; ++c)
+            if ((tss[c] < 6 ? 1 : 2) != chainStride)
+                chainStride = 0;
         groups.resize(ngroups);
         pool.reset(new WorkerPool(std::max(0, nthreads - ngroups))); // the group driver threads take part too
         // stage-1 jobs: FindTriggerFrame's pairing, ref = max(i - off, 0) with off = 1 when the model was
@@ -463,7 +468,12 @@ public:
                 HIPOK(hipStreamWaitEvent(stage1Stream, copied[gi], 0));
             const int n1 = (G.s1 - G.s0) * (F - 1);
             if (n1 > 0) {
-                check(abub_diff_hist_dev(d_frames, d_sigma6, G.d_jobs1, n1, W, H, G.d_hist1, nullptr, 0, stage1Stream),
+                // all cameras on the same frame offset: the job list is F-1 long chains per stack (job i refs the
+                // cur frame of job i - off) and the scan loads every frame row once for both of its jobs
+                check(chainStride > 0
+                          ? abub_diff_hist_chained_dev(d_frames, d_sigma6, G.d_jobs1, n1, W, H, G.d_hist1, F - 1, chainStride,
+                                                       stage1Stream)
+                          : abub_diff_hist_dev(d_frames, d_sigma6, G.d_jobs1, n1, W, H, G.d_hist1, nullptr, 0, stage1Stream),
                       "stage1 K2");
                 HIPOK(hipMemcpyAsync(G.h_hist1, G.d_hist1, (size_t)n1 * 1024, hipMemcpyDeviceToHost, stage1Stream));
             }

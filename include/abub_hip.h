@@ -110,6 +110,15 @@ int abub_fg_compact_dev(const uint8_t *img, int nimg, int W, int H, const int32_
  * Fast path only (abub_fast_path(W) != 0). */
 int abub_fast_path(int W);
 
+/* abub_diff_hist_dev without the stored image (trigger search, AnalyzerUnit.cpp:119-324) plus a hint about the job
+ * list: it consists of blocks of `chain_len` consecutive jobs in which job q takes the cur frame of job q - chain_stride
+ * as its ref and all share a model -- what abub_fill_stack_jobs_dev(first = 1, count = F - 1, ref_offset) produces
+ * with chain_len = F - 1, chain_stride = ref_offset.  The kernels then load every frame row once for the two jobs
+ * that use it.  The hint is verified on the device per chain; a list that does not have the structure gives the same
+ * histograms, only slower.  chain_len = 0: no hint. */
+int abub_diff_hist_chained_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs, int njobs, int W,
+                               int H, uint32_t *hist, int chain_len, int chain_stride, void *stream);
+
 /* The trigger-only form of abub_diff_hist_dev (diff == NULL) keeps a work list in device scratch memory that the
  * library owns, one buffer per (device, stream), grown on demand.  Call this before destroying a stream that was
  * used for such launches (or at any quiet moment) to give its buffer back; it waits for the stream to drain. */

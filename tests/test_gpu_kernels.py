@@ -303,3 +303,36 @@ def test_k2_trigger_only_equals_store_mode_full_size(W, H):
     for k in (0, 5, 12, 19, 21, 22):
         assert torch.equal(torch.bincount(D[k].flatten().to(torch.int64), minlength=256).to(h_store.dtype), h_store[k])
     assert int(h_store[19, 1:].sum()) > W * H // 2  # the dense frame really is dense
+
+
+@pytest.mark.parametrize("W,H,F,off", [(1280, 64, 12, 2), (1680, 40, 9, 2), (256, 48, 7, 1), (1280, 33, 6, 3), (512, 40, 5, 2)])
+def test_k2_chained_trigger_pass(oracle, W, H, F, off):
+    """abub_diff_hist_chained_dev: the stack-structured job list (job i refs the cur frame of job i - off) scanned with
+    shared row loads must give the histograms of the plain entry and of the oracle; a WRONG hint (stride or length that
+    do not describe the list) is detected on the device and still gives the same histograms."""
+    rs = np.random.RandomState(F * 131 + W)
+    nst = 3
+    frames = np.zeros((nst * F, H, W), np.uint8)
+    for s in range(nst):
+        base = rs.randint(30, 200, (H, W))
+        for f in range(F):
+            fr = base + rs.randint(-3, 4, (H, W))
+            k = rs.randint(20, 200)
+            fr[rs.randint(0, H, k), rs.randint(0, W, k)] += rs.randint(5, 12, k)
+            if f >= F // 2:
+                yy, xx = np.ogrid[:H, :W]
+                fr = np.where((yy - H // 2) ** 2 + (xx - W // 3 - 40 * s) ** 2 <= (2 + 3 * (f - F // 2)) ** 2, fr + 40, fr)
+            frames[s * F + f] = np.clip(fr, 0, 255)
+    sigma = rs.randint(0, 3, (2, H, W)).astype(np.uint8)
+    f_d = torch.from_numpy(frames).to(DEV)
+    s6 = hip.sigma6(torch.from_numpy(sigma).to(DEV))
+    jobs = hip.stack_jobs(nst, F, 1, F - 1, off, 2, DEV)
+    plain, _ = hip.diff_hist(f_d, s6, jobs, W, H)
+    jn = jobs.cpu().numpy()
+    _, href = oracle_hists(oracle, frames, sigma, [tuple(r) for r in jn])
+    assert np.array_equal(plain.cpu().numpy().astype(np.uint32), href)
+    for L, S in [(F - 1, off), (F - 1, off + 1), (F - 1, 1), ((F - 1) * nst, off), (1, 1)]:
+        if ((F - 1) * nst) % L:
+            continue
+        got, _ = hip.diff_hist(f_d, s6, jobs, W, H, chain=(L, S))
+        assert torch.equal(got, plain), (L, S)

@@ -43,6 +43,7 @@ int main(int argc, char **argv)
     int F = argc > 1 ? atoi(argv[1]) : 2000, reps = argc > 2 ? atoi(argv[2]) : 5;
     int store = argc > 3 ? atoi(argv[3]) : 0, W = argc > 4 ? atoi(argv[4]) : 1280, H = argc > 5 ? atoi(argv[5]) : 1024;
     int R = argc > 6 ? atoi(argv[6]) : 0;
+    int chain = argc > 8 ? atoi(argv[8]) : 1; // 1: pass the chain hint (jobs f, f+2 share a frame), 0: plain job list
     int sig = argc > 7 ? atoi(argv[7]) : 1; // model sigma: 1 -> ~3.5 supra-threshold noise pixels per row, 2 -> none
     size_t P = (size_t)W * H;
     uint8_t *slab, *sigma, *sigma6, *diff = nullptr;
@@ -67,12 +68,12 @@ int main(int argc, char **argv)
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
     CK(hipEventCreate(&b));
-    AK(abub_diff_hist_dev(slab, sigma6, jobs, njobs, W, H, hist, diff, R, nullptr)); // warm-up
+    if (chain && !store && !R) AK(abub_diff_hist_chained_dev(slab, sigma6, jobs, njobs, W, H, hist, njobs, 2, nullptr)); else AK(abub_diff_hist_dev(slab, sigma6, jobs, njobs, W, H, hist, diff, R, nullptr)); // warm-up
     CK(hipDeviceSynchronize());
     float best = 1e30f, sum = 0;
     for (int r = 0; r < reps; r++) {
         CK(hipEventRecord(a, 0));
-        AK(abub_diff_hist_dev(slab, sigma6, jobs, njobs, W, H, hist, diff, R, nullptr));
+        if (chain && !store && !R) AK(abub_diff_hist_chained_dev(slab, sigma6, jobs, njobs, W, H, hist, njobs, 2, nullptr)); else AK(abub_diff_hist_dev(slab, sigma6, jobs, njobs, W, H, hist, diff, R, nullptr));
         CK(hipEventRecord(b, 0));
         CK(hipEventSynchronize(b));
         float ms;
