@@ -214,8 +214,9 @@ extern "C" int abub_ctx_diff_hist_batch(abub_ctx *c, int ref_offset, int first, 
         return ABUB_OK;
     CCHK(hipSetDevice(c->device));
     CALL(abub_fill_stack_jobs_dev(c->d_jobs, 1, c->F, first, count, ref_offset, 1, c->stream));
-    CALL(abub_diff_hist_dev(c->d_frames, c->d_sigma6, c->d_jobs, count, c->W, c->H, c->d_hist, nullptr,
-                            0, c->stream));
+    // one stack: the whole job list is one block of chains (job q refs the cur frame of job q - ref_offset)
+    CALL(abub_diff_hist_chained_dev(c->d_frames, c->d_sigma6, c->d_jobs, count, c->W, c->H, c->d_hist,
+                                    ref_offset > 0 ? count : 0, ref_offset, c->stream));
     CCHK(hipMemcpyAsync(c->h_hist, c->d_hist, (size_t)count * 256 * sizeof(uint32_t),
                         hipMemcpyDeviceToHost, c->stream));
     CCHK(hipStreamSynchronize(c->stream));
