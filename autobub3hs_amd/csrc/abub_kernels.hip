@@ -2,12 +2,17 @@
 // and their stateless C-ABI launchers (include/abub_hip.h, layer A).
 //
 // Kernel inventory (DESIGN.md section "Kernels"):
-//   K2  k2_rows<NDW,STORE>   fused AnalyzerUnit::ProcessFrame + 256-bin histogram, register-rolling rows
-//   K2g k2_generic           same arithmetic, any size / ROI, LDS tile (also the ROI overload)
-//   K1  k1_welford           Trainer::CalculateMeanSigmaImageVector (float32 Welford, no FMA)
-//   K1b k1b_pair_hist        histogram of sat(f1 - f0) (training entropy veto)
-//   K3  k3_generic           post-trigger |f-mu|-6sigma, 3x3 box, histogram
-//   K4  k4_compact           binarize + foreground index compaction
+//   K2  k2_rows<NDW,STORE,PF,COMPACT>  fused AnalyzerUnit::ProcessFrame + 256-bin histogram, register-rolling rows
+//                                      (optional stored image / fused candidate list; list mode for handed-over rows)
+//       k2_bound_chain / k2_bound_scan trigger-only: proves rows of D zero from a bound, lists the rest
+//       k2_exact_groups                the listed 4-pixel groups, straight from the definition
+//   K2g k2_generic                     same arithmetic, any size / ROI, LDS tile (also the ROI overload)
+//   K1  k1_welford, k1_welford4        Trainer::CalculateMeanSigmaImageVector (float32 Welford, no FMA)
+//   K1b k1b_pair_hist                  histogram of sat(f1 - f0) (training entropy veto)
+//   K3  k3_rows<NDW,STORE>, k3_generic post-trigger |f-mu|-6sigma, 3x3 box, histogram (+ candidate list)
+//   K4  k4_compact, k4_compact_pairs   binarize + foreground index compaction (unfused fallback)
+//       k_pairs_*                      counting-sort grouping of the shared candidate list by image
+//       k_match_ccorr, k_subsat_hist   bellows veto (TrackAFeature terms, image subtraction)
 // No MFMA anywhere: this is integer/byte pixel work (see DESIGN.md "Why no MFMA").
 #include <hip/hip_runtime.h>
 #include <stdint.h>

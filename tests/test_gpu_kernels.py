@@ -336,3 +336,27 @@ def test_k2_chained_trigger_pass(oracle, W, H, F, off):
             continue
         got, _ = hip.diff_hist(f_d, s6, jobs, W, H, chain=(L, S))
         assert torch.equal(got, plain), (L, S)
+
+
+def test_scratch_release_and_reuse():
+    """The trigger-only pass keeps its work list in library-owned scratch keyed by stream: releasing it (twice, and for
+    a stream that never had one) is harmless, and the next launch on that stream allocates again and gives the same
+    histograms."""
+    from autobub3hs_amd import _lib
+
+    W, H, F = 1280, 64, 8
+    fr = synth.render_event(W, H, synth.EventSpec(F, t0=3, bubbles=[(300, 30, 40)]), 9, 0, xp="torch", device=DEV)
+    s6 = hip.sigma6(torch.ones((1, H, W), dtype=torch.uint8, device=DEV))
+    jobs = hip.stack_jobs(1, F, 1, F - 1, 2, 1, DEV)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        h1, _ = hip.diff_hist(fr, s6, jobs, W, H, chain=(F - 1, 2))
+    side.synchronize()
+    L = _lib.lib()
+    assert L.abub_scratch_release(side.cuda_stream) == 0
+    assert L.abub_scratch_release(side.cuda_stream) == 0
+    assert L.abub_scratch_release(torch.cuda.Stream().cuda_stream) == 0
+    with torch.cuda.stream(side):
+        h2, _ = hip.diff_hist(fr, s6, jobs, W, H, chain=(F - 1, 2))
+    side.synchronize()
+    assert torch.equal(h1, h2) and int(h1[:, 1:].sum()) > 0
