@@ -1128,7 +1128,7 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
         const char *e = getenv("ABUB_K2_BOUND"); // 0: always the full row machine (k2_rows)
         bound = e ? atoi(e) : 1;
     }
-    if (bound && !diff && !ca.cthr) {
+    if (bound && !diff && !ca.cthr && (size_t)H * (size_t)(W / 4) < ((size_t)1 << 32)) { // (row, group) codes are 32-bit
         // trigger-only: bound-and-verify (see k2_bound_scan)
         const size_t nunits = (size_t)njobs * nchunks;
         // every chunk may list up to `budget` suspicious groups (then it hands its remaining rows to the row machine),
