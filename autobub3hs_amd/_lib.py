@@ -1,7 +1,7 @@
 """ctypes loader of the in-tree gfx950 library (autobub3hs_amd/libabub_hip.so).
 
 The product path has NO CPU fallback: if the HIP library is missing or cannot be loaded this module
-raises, loudly.  (The CPU oracle lives in oracle/ and is test infrastructure only.)
+raises, loudly.  (No CPU fallback exists in this package.)
 """
 import ctypes as C
 import os

@@ -268,31 +268,6 @@ class Significance:
             pass
 
 
-def smoke(orc):
-    """One small event end to end through the C++ API mirror on cuda:0, checked against the oracle."""
-    from . import synth
-
-    W, H, F = 640, 256, 24
-    spec = synth.EventSpec(F, t0=12, bubbles=[(300, 120, 40)])
-    fr = synth.render_event(W, H, spec, 7, 0)
-    tr = synth.training_pairs(W, H, 6, 0, F)
-    run = Run()
-    for e in range(6):
-        run.add_event(e, 0, np.concatenate([tr[2 * e:2 * e + 2], tr[2 * e:2 * e + 2], tr[2 * e:2 * e + 2]]))
-    st, tss, mu, sg = run.train(0)
-    mu_r, sg_r = orc.welford(tr)
-    assert st == 0 and tss == 12 and np.array_equal(mu, mu_r) and np.array_equal(sg, sg_r)
-    run.add_event(100, 0, fr)
-    staged, state, bubbles, err = run.analyze(100, 0)
-    a = orc.Analyzer(fr, mu_r, sg_r, tss)
-    staged_r, state_r, bubbles_r = a.any_cam_analysis()
-    assert (staged, state) == (staged_r, state_r), (staged, state, staged_r, state_r, err)
-    assert len(bubbles) == len(bubbles_r) and all(
-        [tuple(d[k] for k in "xywh") for d in b["desc"]] == [tuple(d[k] for k in "xywh") for d in r["desc"]]
-        for b, r in zip(bubbles, bubbles_r))
-    run.close()
-
-
 class Pipeline:
     """Run-level batched detect over an HBM-resident slab [E][C][F][H][W] (host/pipeline.cpp)."""
 
