@@ -121,7 +121,8 @@ def main():
     def run_steps(n):
         return ring.run_batches([slab] * n, mu_d, s6_d, stream)
 
-    run_steps(max(args.warmup, ninfl if args.warmup else 0))
+    nwarm = max(args.warmup, ninfl if args.warmup else 0)  # every pipeline object of the ring gets one untimed step
+    run_steps(nwarm)
     fingerprint = pipe.summary()
     if dist:
         dist.barrier()
@@ -208,6 +209,7 @@ def main():
             "events_per_gpu": E, "cams": C, "frames_per_stack": F, "width": W, "height": H,
             "parallelism": f"events sharded over {world} GPU(s), no collective",
             "host_threads": args.threads,
+            "warmup_steps_run": nwarm,
             "steps_in_flight": ninfl,  # stage_ms below are wall times inside one step: with >1 in flight they include
                                        # queueing behind the other steps' kernels and no longer add up to ms_per_step
             "triggered_stacks": n_trig, "bubbles": n_bub,
