@@ -842,37 +842,42 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
             const int tt = t0 + u;
             const int tn = tt + 1 < T ? tt + 1 : T - 1;
             K2C_LOAD(u ^ 1, reflect101(y0 - 2 + tn, H));
-            uint32_t sw[2 * NDW], pw[2 * NDW];
+            // widened frame rows (pw / cw) and frame + sigma6 (ps / cs): each is computed once per frame and serves the
+            // job that has the frame as cur and the job that has it as ref
+            uint32_t sw[2 * NDW], pw[2 * NDW], ps[2 * NDW];
 #pragma unroll
             for (int d = 0; d < NDW; d++) {
                 sw[2 * d] = widen_lo(raw[u][K + 1][d]);
                 sw[2 * d + 1] = widen_hi(raw[u][K + 1][d]);
                 pw[2 * d] = widen_lo(raw[u][0][d]);
                 pw[2 * d + 1] = widen_hi(raw[u][0][d]);
+                ps[2 * d] = pw[2 * d] + sw[2 * d];
+                ps[2 * d + 1] = pw[2 * d + 1] + sw[2 * d + 1];
             }
 #pragma unroll
             for (int t = 0; t < K; t++) {
-                uint32_t cw[2 * NDW];
+                uint32_t cw[2 * NDW], cs[2 * NDW];
 #pragma unroll
                 for (int d = 0; d < NDW; d++) {
                     cw[2 * d] = widen_lo(raw[u][t + 1][d]);
                     cw[2 * d + 1] = widen_hi(raw[u][t + 1][d]);
+                    cs[2 * d] = cw[2 * d] + sw[2 * d];
+                    cs[2 * d + 1] = cw[2 * d + 1] + sw[2 * d + 1];
                 }
                 if (J[t].handover < 0) {
                     uint32_t m[NDW];
 #pragma unroll
-                    for (int g = 0; g < NDW; g++) {
-                        const uint32_t c0 = cw[2 * g], c1 = cw[2 * g + 1], r0 = pw[2 * g], r1 = pw[2 * g + 1];
-                        const uint32_t s0 = sw[2 * g], s1 = sw[2 * g + 1];
-                        m[g] = (pk_subsat(c0, r0 + s0) + pk_subsat(r0, c0 + s0)) +
-                               (pk_subsat(c1, r1 + s1) + pk_subsat(r1, c1 + s1));
-                    }
+                    for (int g = 0; g < NDW; g++) // sat(c - (r + s)) + sat(r - (c + s)), both pairs of the group
+                        m[g] = (pk_subsat(cw[2 * g], ps[2 * g]) + pk_subsat(pw[2 * g], cs[2 * g])) +
+                               (pk_subsat(cw[2 * g + 1], ps[2 * g + 1]) + pk_subsat(pw[2 * g + 1], cs[2 * g + 1]));
                     k2b_row<NDW>(J[t], m, tt >= 4 && tt < T, y0 + tt - 4, active, first_lane, last_lane, lane, ngroups,
                                  budget, pend[t], list, nlist);
                 }
 #pragma unroll
-                for (int j = 0; j < 2 * NDW; j++)
+                for (int j = 0; j < 2 * NDW; j++) {
                     pw[j] = cw[j];
+                    ps[j] = cs[j];
+                }
             }
         }
     }
