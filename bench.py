@@ -191,7 +191,7 @@ def main():
                 break
 
     out = {
-        "metric": "frames/s end-to-end detect @1280x1024 8-bit",
+        "metric": f"frames/s end-to-end detect @{W}x{H} 8-bit",  # BASELINE.json's metric at the default 1280x1024
         "value": value,
         "unit": "frames/s",
         "n_gpus": world,
