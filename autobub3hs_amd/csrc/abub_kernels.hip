@@ -1138,7 +1138,12 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
         const size_t nunits = (size_t)njobs * nchunks;
         // every chunk may list up to `budget` suspicious groups (then it hands its remaining rows to the row machine),
         // so the list can never overflow; 64 M entries = 512 MB at most
-        size_t budget = 512;
+        static int budgetEnv = -1;
+        if (budgetEnv < 0) {
+            const char *e = getenv("ABUB_K2_BUDGET"); // suspects a chunk may list before it hands its rows over
+            budgetEnv = e && atoi(e) > 0 ? atoi(e) : 1024;
+        }
+        size_t budget = (size_t)budgetEnv;
         if (nunits * budget > ((size_t)64 << 20))
             budget = ((size_t)64 << 20) / nunits;
         const size_t cap = nunits * budget;
