@@ -224,6 +224,8 @@ def main():
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
             "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
             "ms_per_launch": k2_ms, "jobs_per_launch": njobs,
+            "note": "frac can exceed 1: the contract's algorithmic accounting charges cur, ref and sigma6 (3*W*H per job) to "
+                    "HBM, but a frame's second use and sigma6 are served on-chip (see traffic: measured HBM bytes per launch)",
         },
     }
 
