@@ -578,14 +578,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER
 // Every pixel is either proven zero or computed with the reference arithmetic, and never twice (a chunk that is
 // handed over drops its pending groups): the histogram is bit-identical to the plain k2_rows pass.
 // Packed halves: a register holds (mass of columns 0,2 | mass of columns 1,3) of a group; all recurrences are linear
-// and stay < 65536 per half (<= 16 * 3 * 2 * 255); the row test folds max-of-halves over the lane's groups, which
+// and stay < 65536 per half (<= 16 * 4 * 2 * 255 with paired groups); the row test folds max-of-halves over the lane's groups, which
 // can only over-estimate, the per-group test on a suspicious row folds exactly.
 // ------------------------------------------------------------------------------------------------
 #define K2B_PEND 512 /* >= the groups of one row (W/4 <= 512) */
 
 template <int NDW>
 struct K2BoundJob { // per-job state of the bound recurrence and of its suspect list (all wave-uniform but b*/Mprev)
-    uint32_t b0[NDW], b1[NDW], b2[NDW], Mprev[NDW];
+    // The recurrence runs on PAIRS of 4-pixel groups (8 columns, the last one alone when NDW is odd): the taps of a
+    // column still reach at most the neighbouring 4-pixel group on either side, so M = left group + own pair + right
+    // group bounds every column of the pair; suspects are listed as their 4-pixel groups.
+    static constexpr int NG = (NDW + 1) / 2;
+    uint32_t b0[NG], b1[NG], b2[NG], Mprev[NG];
     uint32_t npend, spent, hot, jidx;
     int handover; // < 0: scanning; >= 0: first output row left to the row machine (or "nothing to do")
 };
@@ -618,11 +622,14 @@ __device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const uint32_t (&m)[
     uint32_t mR = __builtin_amdgcn_update_dpp(0u, m[0], DPP_WAVE_SHL1, 0xf, 0xf, false);
     mL = first_lane ? m[0] : mL;
     mR = last_lane ? m[NDW - 1] : mR;
-    uint32_t B[NDW];
+    constexpr int NG = K2BoundJob<NDW>::NG;
+    uint32_t B[NG];
     uint32_t worst = 0;
 #pragma unroll
-    for (int g = 0; g < NDW; g++) {
-        const uint32_t M = (g ? m[g - 1] : mL) + m[g] + (g + 1 < NDW ? m[g + 1] : mR);
+    for (int g = 0; g < NG; g++) {
+        const int g0 = 2 * g, g1 = 2 * g + 1 < NDW ? 2 * g + 1 : 2 * g; // first and last 4-pixel group of the pair
+        const uint32_t own = g1 != g0 ? m[g0] + m[g1] : m[g0];
+        const uint32_t M = (g0 ? m[g0 - 1] : mL) + own + (g1 + 1 < NDW ? m[g1 + 1] : mR);
         B[g] = J.b0[g] + M;
         const uint32_t M4 = M << 2;
         J.b0[g] = J.b1[g] + M4;
@@ -635,12 +642,12 @@ __device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const uint32_t (&m)[
     const bool unsure = active && ((worst & 0xffffu) + (worst >> 16)) > 21u; // 6 * (lo + hi) < 128 <=> lo + hi <= 21
     if (!(emit && __builtin_amdgcn_ballot_w64(unsure)))
         return;
-    uint32_t fmask = 0;
+    uint32_t fmask = 0; // one bit per 4-pixel group
     if (active) {
 #pragma unroll
-        for (int g = 0; g < NDW; g++)
+        for (int g = 0; g < NG; g++)
             if ((B[g] & 0xffffu) + (B[g] >> 16) > 21u)
-                fmask |= 1u << g;
+                fmask |= (2 * g + 1 < NDW ? 3u : 1u) << (2 * g);
     }
     const uint32_t c = __builtin_popcount(fmask);
     uint32_t inc = c;
@@ -651,7 +658,7 @@ __device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const uint32_t (&m)[
             inc += v;
     }
     const uint32_t total = __shfl(inc, 63);
-    J.hot += total > 32u; // (same hand-over policy as k2_bound_scan)
+    J.hot += total > 32u; // one row of the row machine costs about as much as 30 exact groups
     if (J.hot >= 4u || J.spent + J.npend + total > budget) {
         J.handover = y;
         return;
@@ -700,7 +707,7 @@ __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ 
 
     K2BoundJob<NDW> J;
 #pragma unroll
-    for (int g = 0; g < NDW; g++)
+    for (int g = 0; g < K2BoundJob<NDW>::NG; g++)
         J.b0[g] = J.b1[g] = J.b2[g] = J.Mprev[g] = 0;
     J.npend = J.spent = J.hot = 0;
     J.jidx = (uint32_t)job;
@@ -810,7 +817,7 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
 #pragma unroll
     for (int t = 0; t < K; t++) {
 #pragma unroll
-        for (int g = 0; g < NDW; g++)
+        for (int g = 0; g < K2BoundJob<NDW>::NG; g++)
             J[t].b0[g] = J[t].b1[g] = J[t].b2[g] = J[t].Mprev[g] = 0;
         J[t].npend = J[t].spent = J[t].hot = 0;
         J[t].handover = t < k ? -1 : 0x7fffffff; // (jobs beyond k do nothing and report nothing)
