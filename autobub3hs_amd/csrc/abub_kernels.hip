@@ -588,7 +588,11 @@ struct K2BoundJob { // per-job state of the bound recurrence and of its suspect 
     // The recurrence runs on PAIRS of 4-pixel groups (8 columns, the last one alone when NDW is odd): the taps of a
     // column still reach at most the neighbouring 4-pixel group on either side, so M = left group + own pair + right
     // group bounds every column of the pair; suspects are listed as their 4-pixel groups.
-    static constexpr int NG = (NDW + 1) / 2;
+#ifndef K2B_GS
+#define K2B_GS 2
+#endif
+    static constexpr int GS = K2B_GS > NDW ? NDW : K2B_GS; // 4-pixel groups per recurrence group
+    static constexpr int NG = (NDW + GS - 1) / GS;
     uint32_t b0[NG], b1[NG], b2[NG], Mprev[NG];
     uint32_t npend, spent, hot, jidx;
     int handover; // < 0: scanning; >= 0: first output row left to the row machine (or "nothing to do")
@@ -627,8 +631,12 @@ __device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const uint32_t (&m)[
     uint32_t worst = 0;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
-        const int g0 = 2 * g, g1 = 2 * g + 1 < NDW ? 2 * g + 1 : 2 * g; // first and last 4-pixel group of the pair
-        const uint32_t own = g1 != g0 ? m[g0] + m[g1] : m[g0];
+        constexpr int GS = K2BoundJob<NDW>::GS;
+        const int g0 = GS * g, g1 = GS * g + GS - 1 < NDW ? GS * g + GS - 1 : NDW - 1; // first and last 4-pixel group
+        uint32_t own = m[g0];
+#pragma unroll
+        for (int q = g0 + 1; q <= g1; q++)
+            own += m[q];
         const uint32_t M = (g0 ? m[g0 - 1] : mL) + own + (g1 + 1 < NDW ? m[g1 + 1] : mR);
         B[g] = J.b0[g] + M;
         const uint32_t M4 = M << 2;
@@ -647,7 +655,7 @@ __device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const uint32_t (&m)[
 #pragma unroll
         for (int g = 0; g < NG; g++)
             if ((B[g] & 0xffffu) + (B[g] >> 16) > 21u)
-                fmask |= (2 * g + 1 < NDW ? 3u : 1u) << (2 * g);
+                fmask |= (((1u << K2BoundJob<NDW>::GS) - 1u) << (K2BoundJob<NDW>::GS * g)) & ((1u << NDW) - 1u);
     }
     const uint32_t c = __builtin_popcount(fmask);
     uint32_t inc = c;
