@@ -909,18 +909,27 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
 }
 
 // one lane per listed group: D for its four pixels, straight from the definition (AnalyzerUnit.cpp:351-370)
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void k2_exact_groups(const uint8_t *__restrict__ frames,
                                                        const uint8_t *__restrict__ sigma6,
                                                        const abub_job *__restrict__ jobs, int W, int H,
                                                        const uint2 *__restrict__ list, const uint32_t *__restrict__ nlist,
-                                                       uint32_t listcap, uint32_t *__restrict__ hist)
+                                                       uint32_t listcap, uint32_t *__restrict__ hist,
+                                                       const int32_t *__restrict__ cthr, uint32_t *pairs, uint32_t pcap,
+                                                       uint32_t *pcount, uint32_t slot_base)
 {
     uint32_t n = *nlist;
     if (n > listcap)
         n = listcap;
     const size_t P = (size_t)W * H;
     const uint32_t ngroups = (uint32_t)W / 4;
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    // with the fused candidate list whole waves iterate together (the reservation below shuffles)
+    const uint32_t nloop = COMPACT ? (n + 63u) & ~63u : n;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < nloop; e += gridDim.x * blockDim.x) {
+        uint32_t Dv[4] = {0, 0, 0, 0};
+        uint32_t cslot = 0, pix0 = 0;
+        int thr = 255;
+        if (e < n) {
         const uint2 en = list[e];
         const abub_job jb = jobs[en.x];
         const int y = (int)(en.y / ngroups), x0 = (int)(en.y % ngroups) * 4;
@@ -972,8 +981,46 @@ __global__ __launch_bounds__(256) void k2_exact_groups(const uint8_t *__restrict
         for (int k = 0; k < 4; k++) {
             const int a = (Sp[k] + 128) >> 8, b = (Sn[k] + 128) >> 8;
             const int d = a > b ? a - b : b - a;
+            Dv[k] = (uint32_t)d;
             if (d)
                 atomicAdd(&hist[(size_t)jb.out * 256 + d], 1u);
+        }
+        if (COMPACT) {
+            cslot = jb.out + slot_base;
+            pix0 = (uint32_t)(y * W + x0);
+            thr = cthr[jb.out];
+        }
+        } // e < n
+        if (COMPACT) { // candidates (value > cut) of the wave's groups: one reservation per wave
+            Compact cp;
+            cp.pairs = pairs;
+            cp.count = pcount;
+            cp.cap = pcap;
+            cp.slot = cslot;
+            cp.thr = thr;
+            uint32_t c = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                c += (int)Dv[k] > thr;
+            const int wl = threadIdx.x & 63;
+            uint32_t inc = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                uint32_t v = __shfl_up(inc, o);
+                if (wl >= o)
+                    inc += v;
+            }
+            const uint32_t total = __shfl(inc, 63);
+            uint32_t base = 0;
+            if (total) {
+                if (wl == 0)
+                    base = atomicAdd(pcount, total);
+                base = __shfl(base, 0);
+            }
+            uint32_t pos = base + inc - c;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                compact_put(cp, pos, Dv[k], pix0 + k);
         }
     }
 }
@@ -1066,12 +1113,16 @@ struct K2ScratchBuf {
 static std::mutex g_scratchMu;
 static std::map<std::pair<int, hipStream_t>, K2ScratchBuf> g_scratch;
 
-static void *k2_scratch(hipStream_t st, size_t bytes)
+// Returns the stream's buffer with g_scratchMu HELD by `hold`: the caller keeps it until the whole launch sequence that
+// uses the buffer is enqueued.  Several host threads may launch on one stream (the run pipeline's stack groups do):
+// their sequences must not interleave, or one would reset the counters and overwrite the list of the other between
+// its kernels.  (Enqueueing takes microseconds; execution is ordered by the stream.)
+static void *k2_scratch(hipStream_t st, size_t bytes, std::unique_lock<std::mutex> &hold)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess)
         return nullptr;
-    std::lock_guard<std::mutex> lock(g_scratchMu);
+    hold = std::unique_lock<std::mutex>(g_scratchMu);
     K2ScratchBuf &b = g_scratch[std::make_pair(dev, st)];
     if (b.n < bytes) {
         if (b.p) {
@@ -1148,7 +1199,7 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
         const char *e = getenv("ABUB_K2_BOUND"); // 0: always the full row machine (k2_rows)
         bound = e ? atoi(e) : 1;
     }
-    if (bound && !diff && !ca.cthr && (size_t)H * (size_t)(W / 4) < ((size_t)1 << 32)) { // (row, group) codes are 32-bit
+    if (bound && !diff && (size_t)H * (size_t)(W / 4) < ((size_t)1 << 32)) { // (row, group) codes are 32-bit
         // trigger-only: bound-and-verify (see k2_bound_scan)
         const size_t nunits = (size_t)njobs * nchunks;
         // every chunk may list up to `budget` suspicious groups (then it hands its remaining rows to the row machine),
@@ -1164,7 +1215,8 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
         const size_t cap = nunits * budget;
         const size_t unitBytes = (nunits * sizeof(uint2) + 255) & ~(size_t)255;
         const size_t bytes = 256 + unitBytes + cap * sizeof(uint2) + 256;
-        uint8_t *scr = (uint8_t *)k2_scratch(st, bytes);
+        std::unique_lock<std::mutex> hold;
+        uint8_t *scr = (uint8_t *)k2_scratch(st, bytes, hold);
         if (!scr)
             return set_err(ABUB_E_HIP, "abub_diff_hist_dev: scratch allocation failed");
         uint32_t *counters = (uint32_t *)scr; // [0] = list entries, [1] = handed-over units
@@ -1199,12 +1251,21 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
             hipLaunchKernelGGL((k2_bound_scan<NDW>), dim3((unsigned)nunits), dim3(64), 0, st, frames, sigma6, jobs, W, H, R,
                                nchunks, list, counters, (uint32_t)budget, units, counters + 1);
         }
-        hipLaunchKernelGGL(k2_exact_groups, dim3(1024), dim3(256), 0, st, frames, sigma6, jobs, W, H, list, counters,
-                           (uint32_t)cap, hist);
         const unsigned g3 = (unsigned)(nunits < 2048 ? nunits : 2048);
-        hipLaunchKernelGGL((k2_rows<NDW, false, 1, false>), dim3(g3), dim3(64), 0, st, frames, sigma6, jobs, W, H, R,
-                           nchunks, hist, (uint8_t *)nullptr, (const int32_t *)nullptr, (uint32_t *)nullptr, 0u,
-                           (uint32_t *)nullptr, 0u, units, counters + 1);
+        if (ca.cthr) { // fused candidate list: the exact kernel and the handed-over rows emit it
+            hipLaunchKernelGGL((k2_exact_groups<true>), dim3(1024), dim3(256), 0, st, frames, sigma6, jobs, W, H, list,
+                               counters, (uint32_t)cap, hist, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base);
+            hipLaunchKernelGGL((k2_rows<NDW, false, 1, true>), dim3(g3), dim3(64), 0, st, frames, sigma6, jobs, W, H, R,
+                               nchunks, hist, (uint8_t *)nullptr, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base, units,
+                               counters + 1);
+        } else {
+            hipLaunchKernelGGL((k2_exact_groups<false>), dim3(1024), dim3(256), 0, st, frames, sigma6, jobs, W, H, list,
+                               counters, (uint32_t)cap, hist, (const int32_t *)nullptr, (uint32_t *)nullptr, 0u,
+                               (uint32_t *)nullptr, 0u);
+            hipLaunchKernelGGL((k2_rows<NDW, false, 1, false>), dim3(g3), dim3(64), 0, st, frames, sigma6, jobs, W, H, R,
+                               nchunks, hist, (uint8_t *)nullptr, (const int32_t *)nullptr, (uint32_t *)nullptr, 0u,
+                               (uint32_t *)nullptr, 0u, units, counters + 1);
+        }
         return ABUB_OK;
     }
     // prefetch depth 1 won on MI355X: depth 2/3 rings cost a wave of occupancy and ran 10-17 % slower
