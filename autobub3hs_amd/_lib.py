@@ -42,6 +42,8 @@ SIGNATURES = {
     "abub_fast_path": (_i, [_i]),
     "abub_scratch_release": (_i, [_vp]),
     "abub_diff_hist_chained_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
+    "abub_diff_hist_chained_store_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "abub_k2_set_option": (_i, [C.c_char_p, _i]),
     "abub_diff_hist_compact_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp]),
     "abub_posttrig_compact_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp]),
     "abub_pairs_group_dev": (_i, [_vp, _vp, C.c_uint32, _i, _vp, _vp, _vp, _vp, _vp]),

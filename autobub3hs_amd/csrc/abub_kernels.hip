@@ -609,6 +609,7 @@ __device__ __forceinline__ void k2b_flush(K2BoundJob<NDW> &J, uint32_t *pend, ui
     if (lane == 0)
         base = atomicAdd(nlist, J.npend);
     base = __shfl(base, 0);
+#pragma unroll 1 // rare path: unrolled, its LDS reads would set the kernel's register allocation
     for (uint32_t i = lane; i < J.npend; i += 64)
         list[base + i] = make_uint2(J.jidx, pend[i]);
     __syncthreads();
@@ -682,13 +683,26 @@ __device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const uint32_t (&m)[
     J.npend += total;
 }
 
+// Store mode of the bound-and-verify pass: a row the scan is responsible for (everything above the hand-over row) is
+// written as zeros by the scan itself -- proven rows ARE zero, and the few suspect groups of a row are overwritten by
+// k2_exact_groups, which runs after the scan on the same stream.
 template <int NDW>
+__device__ __forceinline__ void k2b_store_zero_row(uint8_t *__restrict__ row)
+{
+    uint32_t *po = reinterpret_cast<uint32_t *>(row);
+#pragma unroll
+    for (int d = 0; d < NDW; d++)
+        po[d] = 0;
+}
+
+template <int NDW, bool STORE>
 __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ frames,
                                                     const uint8_t *__restrict__ sigma6,
                                                     const abub_job *__restrict__ jobs, int W, int H,
                                                     int rows_per_chunk, int nchunks, uint2 *__restrict__ list,
                                                     uint32_t *__restrict__ nlist, uint32_t budget,
-                                                    uint2 *__restrict__ units, uint32_t *__restrict__ nunits)
+                                                    uint2 *__restrict__ units, uint32_t *__restrict__ nunits,
+                                                    uint8_t *__restrict__ diff)
 {
     constexpr int NP = 2 * NDW;
     __shared__ uint32_t pend[K2B_PEND];
@@ -720,6 +734,7 @@ __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ 
     J.npend = J.spent = J.hot = 0;
     J.jidx = (uint32_t)job;
     J.handover = -1;
+    uint8_t *dbase = STORE ? diff + (size_t)jb.out * P + xoff : nullptr;
 
     RowIn<NDW> ring[2];
     k2_load_row<NDW>(ring[0], cur, ref, sg, reflect101(y0 - 2, H), W, xoff);
@@ -739,6 +754,8 @@ __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ 
                     m[g] = (Xp[2 * g] + Xn[2 * g]) + (Xp[2 * g + 1] + Xn[2 * g + 1]);
                 k2b_row<NDW>(J, m, tt >= 4 && tt < T, y0 + tt - 4, active, first_lane, last_lane, lane, ngroups, budget,
                              pend, list, nlist);
+                if (STORE && tt >= 4 && tt < T && J.handover < 0 && active)
+                    k2b_store_zero_row<NDW>(dbase + (ptrdiff_t)(y0 + tt - 4) * W);
             }
         }
     }
@@ -757,13 +774,14 @@ __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ 
 // The chain property is only a hint: the wave checks it on the job records and hands units it cannot chain to the row
 // machine, so any job list gives the same histograms as k2_bound_scan / k2_rows.
 // ------------------------------------------------------------------------------------------------
-template <int NDW, int K>
+template <int NDW, int K, bool STORE>
 __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__ frames,
                                                      const uint8_t *__restrict__ sigma6,
                                                      const abub_job *__restrict__ jobs, int L, int S, int nslot, int W,
                                                      int H, int rows_per_chunk, int nchunks, uint2 *__restrict__ list,
                                                      uint32_t *__restrict__ nlist, uint32_t budget,
-                                                     uint2 *__restrict__ units, uint32_t *__restrict__ nunits)
+                                                     uint2 *__restrict__ units, uint32_t *__restrict__ nunits,
+                                                     uint8_t *__restrict__ diff)
 {
     __shared__ uint32_t pend[K][K2B_PEND];
     const int lane = threadIdx.x;
@@ -817,6 +835,10 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
     const bool first_lane = lane == 0;
     const bool last_lane = lane == nl - 1;
     const int xoff = active ? lane * 4 * NDW : 0;
+    uint8_t *dbase[K];
+#pragma unroll
+    for (int t = 0; t < K; t++)
+        dbase[t] = STORE ? diff + (size_t)jb[t].out * P + xoff : nullptr;
     int y1 = y0 + rows_per_chunk;
     if (y1 > H)
         y1 = H;
@@ -887,6 +909,8 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
                                (pk_subsat(cw[2 * g + 1], ps[2 * g + 1]) + pk_subsat(pw[2 * g + 1], cs[2 * g + 1]));
                     k2b_row<NDW>(J[t], m, tt >= 4 && tt < T, y0 + tt - 4, active, first_lane, last_lane, lane, ngroups,
                                  budget, pend[t], list, nlist);
+                    if (STORE && tt >= 4 && tt < T && J[t].handover < 0 && active)
+                        k2b_store_zero_row<NDW>(dbase[t] + (ptrdiff_t)(y0 + tt - 4) * W);
                 }
 #pragma unroll
                 for (int j = 0; j < 2 * NDW; j++) {
@@ -909,14 +933,14 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
 }
 
 // one lane per listed group: D for its four pixels, straight from the definition (AnalyzerUnit.cpp:351-370)
-template <bool COMPACT>
+template <bool COMPACT, bool STORE>
 __global__ __launch_bounds__(256) void k2_exact_groups(const uint8_t *__restrict__ frames,
                                                        const uint8_t *__restrict__ sigma6,
                                                        const abub_job *__restrict__ jobs, int W, int H,
                                                        const uint2 *__restrict__ list, const uint32_t *__restrict__ nlist,
                                                        uint32_t listcap, uint32_t *__restrict__ hist,
                                                        const int32_t *__restrict__ cthr, uint32_t *pairs, uint32_t pcap,
-                                                       uint32_t *pcount, uint32_t slot_base)
+                                                       uint32_t *pcount, uint32_t slot_base, uint8_t *__restrict__ diff)
 {
     uint32_t n = *nlist;
     if (n > listcap)
@@ -985,6 +1009,9 @@ __global__ __launch_bounds__(256) void k2_exact_groups(const uint8_t *__restrict
             if (d)
                 atomicAdd(&hist[(size_t)jb.out * 256 + d], 1u);
         }
+        if (STORE) // (the scan wrote this row as zeros; x0 is a multiple of 4 and W % 4 == 0: an aligned dword)
+            *reinterpret_cast<uint32_t *>(diff + (size_t)jb.out * P + (size_t)y * W + x0) =
+                Dv[0] | (Dv[1] << 8) | (Dv[2] << 16) | (Dv[3] << 24);
         if (COMPACT) {
             cslot = jb.out + slot_base;
             pix0 = (uint32_t)(y * W + x0);
@@ -1189,27 +1216,67 @@ static void launch_k2_rows_pf(const uint8_t *frames, const uint8_t *sigma6, cons
 #undef K2_LAUNCH
 }
 
+// Tuning knobs of the K2 launchers.  Defaults come from the environment once (ABUB_K2_BOUND, ABUB_K2_CHAIN,
+// ABUB_K2_BUDGET, ABUB_K2_PF); abub_k2_set_option() overrides them at run time (tests and benches switch between
+// the bound-and-verify pass and the plain row machine inside one process).
+struct K2Options {
+    int bound = 1;     // 0: always the full row machine (k2_rows); 1: bound-and-verify (trigger-only AND store mode)
+    int chain = 2;     // jobs per wave in the chained scan (2 or 3; 0 = never chain)
+    int budget = 1024; // suspects a chunk may list before it hands its rows over
+    int pf = 1;        // software-prefetch depth of the row machine in rows (1 or 2)
+    bool loaded = false;
+};
+static K2Options g_k2opt;
+static std::mutex g_k2optMu;
+static K2Options k2_options()
+{
+    std::lock_guard<std::mutex> lock(g_k2optMu);
+    if (!g_k2opt.loaded) {
+        if (const char *e = getenv("ABUB_K2_BOUND"))
+            g_k2opt.bound = atoi(e);
+        if (const char *e = getenv("ABUB_K2_CHAIN"))
+            g_k2opt.chain = atoi(e);
+        if (const char *e = getenv("ABUB_K2_BUDGET"))
+            if (atoi(e) > 0)
+                g_k2opt.budget = atoi(e);
+        if (const char *e = getenv("ABUB_K2_PF"))
+            g_k2opt.pf = atoi(e);
+        g_k2opt.loaded = true;
+    }
+    return g_k2opt;
+}
+
+extern "C" int abub_k2_set_option(const char *name, int value)
+{
+    if (!name)
+        return set_err(ABUB_E_INVALID, "abub_k2_set_option: null name");
+    (void)k2_options();
+    std::lock_guard<std::mutex> lock(g_k2optMu);
+    if (!strcmp(name, "bound"))
+        g_k2opt.bound = value;
+    else if (!strcmp(name, "chain"))
+        g_k2opt.chain = value;
+    else if (!strcmp(name, "budget") && value > 0)
+        g_k2opt.budget = value;
+    else if (!strcmp(name, "pf"))
+        g_k2opt.pf = value;
+    else
+        return set_err(ABUB_E_INVALID, "abub_k2_set_option: unknown option or bad value");
+    return ABUB_OK;
+}
+
 template <int NDW>
 static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
                            int njobs, int W, int H, int R, int nchunks, uint32_t *hist, uint8_t *diff,
                            const CompactArgs &ca, hipStream_t st)
 {
-    static int bound = -1;
-    if (bound < 0) {
-        const char *e = getenv("ABUB_K2_BOUND"); // 0: always the full row machine (k2_rows)
-        bound = e ? atoi(e) : 1;
-    }
-    if (bound && !diff && (size_t)H * (size_t)(W / 4) < ((size_t)1 << 32)) { // (row, group) codes are 32-bit
-        // trigger-only: bound-and-verify (see k2_bound_scan)
+    const K2Options opt = k2_options();
+    if (opt.bound && (size_t)H * (size_t)(W / 4) < ((size_t)1 << 32)) { // (row, group) codes are 32-bit
+        // bound-and-verify (see k2_bound_scan); with `diff` the scan also writes the rows it proves (or lists)
         const size_t nunits = (size_t)njobs * nchunks;
         // every chunk may list up to `budget` suspicious groups (then it hands its remaining rows to the row machine),
         // so the list can never overflow; 64 M entries = 512 MB at most
-        static int budgetEnv = -1;
-        if (budgetEnv < 0) {
-            const char *e = getenv("ABUB_K2_BUDGET"); // suspects a chunk may list before it hands its rows over
-            budgetEnv = e && atoi(e) > 0 ? atoi(e) : 1024;
-        }
-        size_t budget = (size_t)budgetEnv;
+        size_t budget = (size_t)opt.budget;
         if (nunits * budget > ((size_t)64 << 20))
             budget = ((size_t)64 << 20) / nunits;
         const size_t cap = nunits * budget;
@@ -1223,59 +1290,65 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
         uint2 *units = (uint2 *)(scr + 256);
         uint2 *list = (uint2 *)(scr + 256 + unitBytes);
         HIPCHK(hipMemsetAsync(counters, 0, 2 * sizeof(uint32_t), st));
-        static int chainK = -1;
-        if (chainK < 0) {
-            const char *e = getenv("ABUB_K2_CHAIN"); // jobs per wave in the chained scan (1..4; 0 = never chain)
-            chainK = e ? atoi(e) : 2;
-        }
         const int L = ca.chain_len, S = ca.chain_stride;
-        if (chainK > 0 && L > 0 && S > 0 && S <= 8 && njobs % L == 0) {
-            const int Kc = chainK > 4 ? 4 : chainK;
+        if (opt.chain >= 2 && L > 0 && S > 0 && S <= 8 && njobs % L == 0) {
+            const int Kc = opt.chain >= 3 ? 3 : 2;
             int nslot = 0;
             for (int r = 0; r < S; r++) {
                 const int nr = (L - r + S - 1) / S;
                 nslot += nr > 0 ? (nr + Kc - 1) / Kc : 0;
             }
             const dim3 grid((unsigned)((size_t)(njobs / L) * nslot * nchunks));
-#define K2C_LAUNCH(KK)                                                                                              \
-    hipLaunchKernelGGL((k2_bound_chain<NDW, KK>), grid, dim3(64), 0, st, frames, sigma6, jobs, L, S, nslot, W, H, R, \
-                       nchunks, list, counters, (uint32_t)budget, units, counters + 1)
-            switch (Kc) {
-            case 1: K2C_LAUNCH(1); break;
-            case 2: K2C_LAUNCH(2); break;
-            case 3: K2C_LAUNCH(3); break;
-            default: K2C_LAUNCH(4); break;
+#define K2C_LAUNCH(KK, ST)                                                                                          \
+    hipLaunchKernelGGL((k2_bound_chain<NDW, KK, ST>), grid, dim3(64), 0, st, frames, sigma6, jobs, L, S, nslot, W,  \
+                       H, R, nchunks, list, counters, (uint32_t)budget, units, counters + 1, diff)
+            if (Kc == 3) {
+                if (diff)
+                    K2C_LAUNCH(3, true);
+                else
+                    K2C_LAUNCH(3, false);
+            } else {
+                if (diff)
+                    K2C_LAUNCH(2, true);
+                else
+                    K2C_LAUNCH(2, false);
             }
 #undef K2C_LAUNCH
         } else {
-            hipLaunchKernelGGL((k2_bound_scan<NDW>), dim3((unsigned)nunits), dim3(64), 0, st, frames, sigma6, jobs, W, H, R,
-                               nchunks, list, counters, (uint32_t)budget, units, counters + 1);
+            if (diff)
+                hipLaunchKernelGGL((k2_bound_scan<NDW, true>), dim3((unsigned)nunits), dim3(64), 0, st, frames, sigma6, jobs,
+                                   W, H, R, nchunks, list, counters, (uint32_t)budget, units, counters + 1, diff);
+            else
+                hipLaunchKernelGGL((k2_bound_scan<NDW, false>), dim3((unsigned)nunits), dim3(64), 0, st, frames, sigma6, jobs,
+                                   W, H, R, nchunks, list, counters, (uint32_t)budget, units, counters + 1, diff);
         }
         const unsigned g3 = (unsigned)(nunits < 2048 ? nunits : 2048);
-        if (ca.cthr) { // fused candidate list: the exact kernel and the handed-over rows emit it
-            hipLaunchKernelGGL((k2_exact_groups<true>), dim3(1024), dim3(256), 0, st, frames, sigma6, jobs, W, H, list,
-                               counters, (uint32_t)cap, hist, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base);
-            hipLaunchKernelGGL((k2_rows<NDW, false, 1, true>), dim3(g3), dim3(64), 0, st, frames, sigma6, jobs, W, H, R,
-                               nchunks, hist, (uint8_t *)nullptr, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base, units,
-                               counters + 1);
+        // the listed groups exactly, then the handed-over rows through the row machine's list mode; with the fused
+        // candidate list (cthr) both emit the candidates, with `diff` both write their pixels
+#define K2X_LAUNCH(CO, ST)                                                                                           \
+    hipLaunchKernelGGL((k2_exact_groups<CO, ST>), dim3(1024), dim3(256), 0, st, frames, sigma6, jobs, W, H, list,    \
+                       counters, (uint32_t)cap, hist, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base, diff);      \
+    hipLaunchKernelGGL((k2_rows<NDW, ST, 1, CO>), dim3(g3), dim3(64), 0, st, frames, sigma6, jobs, W, H, R, nchunks,  \
+                       hist, diff, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base, units, counters + 1)
+        if (ca.cthr) {
+            if (diff) {
+                K2X_LAUNCH(true, true);
+            } else {
+                K2X_LAUNCH(true, false);
+            }
         } else {
-            hipLaunchKernelGGL((k2_exact_groups<false>), dim3(1024), dim3(256), 0, st, frames, sigma6, jobs, W, H, list,
-                               counters, (uint32_t)cap, hist, (const int32_t *)nullptr, (uint32_t *)nullptr, 0u,
-                               (uint32_t *)nullptr, 0u);
-            hipLaunchKernelGGL((k2_rows<NDW, false, 1, false>), dim3(g3), dim3(64), 0, st, frames, sigma6, jobs, W, H, R,
-                               nchunks, hist, (uint8_t *)nullptr, (const int32_t *)nullptr, (uint32_t *)nullptr, 0u,
-                               (uint32_t *)nullptr, 0u, units, counters + 1);
+            if (diff) {
+                K2X_LAUNCH(false, true);
+            } else {
+                K2X_LAUNCH(false, false);
+            }
         }
+#undef K2X_LAUNCH
         return ABUB_OK;
     }
     // prefetch depth 1 won on MI355X: depth 2/3 rings cost a wave of occupancy and ran 10-17 % slower
     // (measured in round 1, see DESIGN.md "Tuning log")
-    static int pf = -1;
-    if (pf < 0) {
-        const char *e = getenv("ABUB_K2_PF"); // tuning knob: software-prefetch depth in rows (1 or 2)
-        pf = e ? atoi(e) : 1;
-    }
-    if (pf == 2)
+    if (opt.pf == 2)
         launch_k2_rows_pf<NDW, 2>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st);
     else
         launch_k2_rows_pf<NDW, 1>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st);
@@ -1356,6 +1429,18 @@ extern "C" int abub_diff_hist_chained_dev(const uint8_t *frames, const uint8_t *
     ca.chain_len = chain_len;
     ca.chain_stride = chain_stride;
     return diff_hist_impl(frames, sigma6, jobs, njobs, W, H, hist, nullptr, 0, ca, stream);
+}
+
+extern "C" int abub_diff_hist_chained_store_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
+                                                int njobs, int W, int H, uint32_t *hist, uint8_t *diff, int chain_len,
+                                                int chain_stride, void *stream)
+{
+    if (chain_len < 0 || chain_stride < 0 || !diff)
+        return set_err(ABUB_E_INVALID, "abub_diff_hist_chained_store_dev: bad arguments");
+    CompactArgs ca = {nullptr, nullptr, 0, nullptr, 0};
+    ca.chain_len = chain_len;
+    ca.chain_stride = chain_stride;
+    return diff_hist_impl(frames, sigma6, jobs, njobs, W, H, hist, diff, 0, ca, stream);
 }
 
 extern "C" int abub_fast_path(int W) { return pick_ndw(W) != 0; }

@@ -52,7 +52,12 @@ def diff_hist(frames, sigma6_, jobs, W, H, store=False, rows_per_chunk=0, hist=N
     if store and diff is None:
         diff = torch.empty((n, H, W), dtype=torch.uint8, device=frames.device)
     if chain is not None:
-        assert not store and rows_per_chunk == 0
+        assert rows_per_chunk == 0
+        if store:
+            _lib.check(_lib.lib().abub_diff_hist_chained_store_dev(_ptr(frames), _ptr(sigma6_), _ptr(jobs), n, W, H,
+                                                                   _ptr(hist), _ptr(diff), int(chain[0]), int(chain[1]),
+                                                                   _stream()), "abub_diff_hist_chained_store_dev")
+            return hist, diff
         _lib.check(_lib.lib().abub_diff_hist_chained_dev(_ptr(frames), _ptr(sigma6_), _ptr(jobs), n, W, H, _ptr(hist),
                                                          int(chain[0]), int(chain[1]), _stream()),
                    "abub_diff_hist_chained_dev")
@@ -61,6 +66,11 @@ def diff_hist(frames, sigma6_, jobs, W, H, store=False, rows_per_chunk=0, hist=N
                                              _ptr(diff) if store else None, rows_per_chunk, _stream()),
                "abub_diff_hist_dev")
     return hist, (diff if store else None)
+
+
+def k2_set_option(name, value):
+    """Run-time K2 launcher knob ("bound", "chain", "budget", "pf"); results never depend on them."""
+    _lib.check(_lib.lib().abub_k2_set_option(name.encode(), int(value)), "abub_k2_set_option")
 
 
 def diff_roi(slab, cur, ref, sigma6_, W, H, roi):

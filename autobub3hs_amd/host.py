@@ -140,6 +140,21 @@ class Run:
         H, W = mu.shape
         lib().abh_set_model(self._h, cam, mu.ctypes.data_as(_u8p), sigma.ctypes.data_as(_u8p), W, H, int(tss))
 
+    def probe_frame_stats(self, event, cam, imgs):
+        """Test hook (abub::AnalyzerProbe): per image the 128-bin entropy, its z-score over the images so far and the
+        256-bin significance, through the private AnalyzerUnit members that the reference compiles but never calls
+        (AnalyzerUnit.cpp:386-433) -> float64 [n,3]."""
+        L = lib()
+        L.abh_probe_frame_stats.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, _dp]
+        imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
+        n, H, W = imgs.shape
+        out = np.zeros((n, 3), np.float64)
+        rc = L.abh_probe_frame_stats(self._h, str(event).encode(), cam, imgs.ctypes.data_as(_u8p), n, W, H,
+                                     out.ctypes.data_as(_dp))
+        if rc != 0:
+            raise RuntimeError(f"abh_probe_frame_stats rc={rc}: " + L.abh_last_error(self._h).decode())
+        return out
+
     def analyze(self, event, cam, maskdir=""):
         L = lib()
         staged = L.abh_analyze(self._h, str(event).encode(), cam, maskdir.encode())

@@ -206,6 +206,11 @@ double CalcMean(std::vector<num> &vec, int size)
     return sum / size;
 }
 
+// `val * val` in the element type (AnalyzerUnit.cpp:529): for int it wraps above 46340 on the reference's platform;
+// spelled out in unsigned arithmetic so that the wrap is defined behaviour here
+static double squareLikeUpstream(double v) { return v * v; }
+static double squareLikeUpstream(int v) { return (double)(int)((unsigned)v * (unsigned)v); }
+
 template <typename num>
 double CalcStdDev(std::vector<num> &vec, double mean, int size)
 {
@@ -213,7 +218,7 @@ double CalcStdDev(std::vector<num> &vec, double mean, int size)
         size = (int)vec.size();
     double sum = 0;
     for (num &val : vec)
-        sum += val * val;
+        sum += squareLikeUpstream(val);
     return std::sqrt(sum / size - mean * mean);
 }
 template double CalcMean<double>(std::vector<double> &, int);

@@ -71,7 +71,43 @@ int anyCamAnalysis(AnalyzerUnit *A, Run *run)
 
 } // namespace
 
+// test hook for the per-frame statistics that are private in AnalyzerUnit and dead upstream (128-bin entropy and its
+// z-score, AnalyzerUnit.cpp:386-433; the image overload of calculateSignificanceFrame :435-504)
+namespace abub {
+struct AnalyzerProbe {
+    static float entropy(AnalyzerUnit &A, cv::Mat &m) { return A.calculateEntropyFrame(m, false); }
+    static double entropySignificance(AnalyzerUnit &A, cv::Mat &m, bool store) { return A.calculateEntropySignificance(m, store, false); }
+    static double significance(AnalyzerUnit &A, cv::Mat &m, bool store) { return A.calculateSignificanceFrame(m, store, false); }
+};
+} // namespace abub
+
 extern "C" {
+
+// feeds `n` images [n][H][W] through an analyzer of (ev, cam): out[3*k] = 128-bin entropy of image k, out[3*k+1] =
+// its z-score over the history so far (stored), out[3*k+2] = the 256-bin significance (stored)
+int abh_probe_frame_stats(void *r, const char *ev, int cam, const uint8_t *imgs, int n, int W, int H, double *out)
+{
+    Run *run = (Run *)r;
+    auto it = run->trainers.find(cam);
+    if (it == run->trainers.end() || !it->second)
+        return -100;
+    Trainer *t = it->second;
+    try {
+        L3Localizer A(ev, "", cam, true, &t, "", run->parser->clone());
+        for (int k = 0; k < n; ++k) {
+            cv::Mat m(H, W, CV_8U);
+            std::memcpy(m.data, imgs + (size_t)k * W * H, (size_t)W * H);
+            out[3 * k] = abub::AnalyzerProbe::entropy(A, m);
+            out[3 * k + 1] = abub::AnalyzerProbe::entropySignificance(A, m, true);
+            out[3 * k + 2] = abub::AnalyzerProbe::significance(A, m, true);
+        }
+    } catch (std::exception &e) {
+        run->error = e.what();
+        return -1;
+    }
+    abub::DeviceContext::releaseThread();
+    return 0;
+}
 
 void *abh_run_new()
 {

@@ -169,3 +169,29 @@ def training_pairs(W, H, n_events, cam, F, xp="numpy", device=None, **kw):
             v = bg + frame_noise(W, H, ev_seed * 131 + f, xp, device)
             out[2 * e + f] = be.to_u8(be.clip(v, 0, 255))
     return out
+
+
+def long_stack(N, W, H, xp="numpy", device=None, out=None, first=0, seed=BASE_SEED):
+    """One long contiguous stack for the kernel microbench (BASELINE configs[2], SURVEY 8d "Config 3"): background +
+    per-frame noise as above, and a bright disc (+40 ADU, radius 2..33) that grows over the second half of every
+    64-frame block at a position that changes from block to block.  Frames `first .. first+N-1` -> uint8 [N,H,W]."""
+    be = _backend(xp)
+    bg = background(W, H, seed, xp, device)
+    if out is None:
+        out = be.empty_u8((N, H, W), device)
+    x = be.arange(W, device)[None, :]
+    y = be.arange(H, device)[:, None]
+    for k in range(N):
+        f = first + k
+        v = bg + frame_noise(W, H, seed * 977 + f, xp, device)
+        ph = f % 64
+        if ph >= 32:
+            blk = f // 64
+            cx, cy, r = 200 + (blk * 37) % max(1, W - 400), 150 + (blk * 53) % max(1, H - 300), 2 + ph - 32
+            x0, x1, y0, y1 = max(cx - r, 0), min(cx + r + 1, W), max(cy - r, 0), min(cy + r + 1, H)
+            dx = x[:, x0:x1] - cx
+            dy = y[y0:y1] - cy
+            sub = v[y0:y1, x0:x1]
+            v[y0:y1, x0:x1] = be.where(dx * dx + dy * dy <= r * r, sub + 40, sub)
+        out[k] = be.to_u8(be.clip(v, 0, 255))
+    return out

@@ -3,17 +3,24 @@
 
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`, one process per
 GPU (torch.distributed / RCCL only for the barrier and the max-over-ranks reduction: the data path
-has no collective, events shard embarrassingly), rank 0 prints ONE JSON line.
+has no collective, events shard embarrassingly), rank 0 prints ONE JSON line.  With --gpus N > 1 and no
+launcher environment (WORLD_SIZE unset) this process only spawns `python -m torch.distributed.run` with N
+ranks of itself, relays rank 0's line and exits with the worst return code; it never touches HIP itself.
 
 Workload at N=1 (BASELINE.json configs[1], SURVEY.md 8d "Config 2"): one synthetic 40l-19-like run,
 E events x cams {0,1} x F=41 frames of 1280x1024 u8, resident in HBM before the timed region.
 A "step" is one pass of the detect path over the whole run.  Steps are software-pipelined (--inflight, default 3:
-host.PipelineRing): the host stages of step k run while the GPU works on step k+1; all K steps start and finish
-inside the timed region.
+host.PipelineRing): the host stages of step k run while the GPU works on step k+1; all K steps of a block start
+and finish inside that block's timed region.  The K-step block (barrier + synchronize on both sides, max over
+ranks) is repeated until --min-seconds have been measured; `ms_per_step` / `value` are the MEDIAN block.
+
+Also reported (config.microbench): BASELINE configs[2], the fused kernel alone on a 10k-frame slab, store mode and
+trigger-only mode, bound-and-verify and the plain row machine (the dense-regime worst case).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,7 +31,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -42,105 +49,250 @@ def parse():
                     help="steps in flight at once (each on its own pipeline object and host thread)")
     ap.add_argument("--stream-steps", type=int, default=2,
                     help="extra steps with the run uploaded from pinned host memory (PCIe-inclusive rate; 0 = skip)")
-    return ap.parse_args()
+    ap.add_argument("--min-seconds", type=float, default=2.0,
+                    help="repeat the timed K-step block until this much time has been measured (0 = one block)")
+    ap.add_argument("--max-blocks", type=int, default=400)
+    ap.add_argument("--micro-frames", type=int, default=10000,
+                    help="frames of the configs[2] kernel microbench slab (0 = skip)")
+    ap.add_argument("--latency-steps", type=int, default=5, help="steps run one at a time for the latency figure (0 = skip)")
+    ap.add_argument("--dry", action="store_true",
+                    help="no GPU work: every rank only walks the launch / barrier / max-over-ranks / report protocol "
+                         "(rehearsal of the multi-rank path on CPU with ABUB_BENCH_BACKEND=gloo)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """--gpus N > 1 outside a launcher: start N ranks of this script, relay rank 0's JSON line, propagate the worst rc.
+    Nothing here imports torch.cuda or calls HIP (a process that has initialised the GPU must not exec/fork workers)."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in p.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if line:
+        print(line)
+    elif rc == 0:
+        rc = 3
+        print("bench.py: the ranks finished without a result line", file=sys.stderr)
+    sys.exit(rc)
+
+
+def gather_floats(x, world, rank, dist):
+    if not dist:
+        return [x]
+    out = [None] * world
+    dist.all_gather_object(out, float(x))
+    return out
 
 
 def main():
     args = parse()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        self_launch(args)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(world_env or "1")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
+
     import numpy as np
     import torch
 
-    from autobub3hs_amd import hip, shard, synth
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-        sys.exit(2)
-    ndev = torch.cuda.device_count()
-    if ndev == 0:
-        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
-    local = local % ndev  # (rehearsals of N ranks on a smaller box share devices; see ABUB_BENCH_BACKEND)
-    torch.cuda.set_device(local)
-    dev = f"cuda:{local}"
-    dist = None
     backend = os.environ.get("ABUB_BENCH_BACKEND", "nccl")  # nccl == RCCL on ROCm; gloo only for rehearsals
+    dev = None
+    if not args.dry:
+        ndev = torch.cuda.device_count()
+        if ndev == 0:
+            raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+        local = local % ndev  # (rehearsals of N ranks on a smaller box share devices; see ABUB_BENCH_BACKEND)
+        torch.cuda.set_device(local)
+        dev = f"cuda:{local}"
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
-        if backend == "nccl":
+        if backend == "nccl" and not args.dry:
             dist.init_process_group("nccl", device_id=torch.device(dev))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group("gloo")
+    red_dev = dev if (backend == "nccl" and not args.dry) else None
+
+    from autobub3hs_amd import shard
 
     W, H, F, E, C = args.width, args.height, args.frames, args.events, args.cams
     P = W * H
     S = E * C  # stacks on this rank
 
-    # ---- synthetic run, generated straight into HBM (rank r owns events r, r+N, r+2N, ...) ----------
-    t0 = time.time()
-    slab = torch.empty((S, F, H, W), dtype=torch.uint8, device=dev)
-    specs = []
-    bgs = [synth.background(W, H, synth.BASE_SEED + c, "torch", dev) for c in range(C)]
-    ev_ids = shard.global_event_ids(E, rank, world)  # round-robin over ranks, like schedule(static,1)
-    for e in range(E):
-        ev = ev_ids[e]
+    def sync():
+        if not args.dry:
+            torch.cuda.synchronize()
+
+    def timed_block(fn):
+        """barrier + synchronize, fn(), synchronize + barrier; returns (max-over-ranks seconds, this rank's own
+        seconds up to its synchronize -- before it waits for the others --, fn's result)"""
+        if dist:
+            dist.barrier()
+        sync()
+        t = time.perf_counter()
+        r = fn()
+        sync()
+        own = time.perf_counter() - t
+        if dist:
+            dist.barrier()
+        return shard.max_over_ranks(time.perf_counter() - t, red_dev), own, r
+
+    if args.dry:
+        # protocol rehearsal: a "step" is a short sleep whose length depends on the rank (a visible straggler)
+        def run_steps(n):
+            time.sleep(n * 0.002 * (1 + rank))
+            return []
+
+        run_steps(args.warmup)
+        gen_s, nwarm, ninfl = 0.0, args.warmup, 1
+        fingerprint, pipes, pipe = [], [], None
+    else:
+        from autobub3hs_amd import hip, host, synth
+
+        # ---- synthetic run, generated straight into HBM (rank r owns events r, r+N, r+2N, ...) ----------
+        t0 = time.time()
+        slab = torch.empty((S, F, H, W), dtype=torch.uint8, device=dev)
+        bgs = [synth.background(W, H, synth.BASE_SEED + c, "torch", dev) for c in range(C)]
+        ev_ids = shard.global_event_ids(E, rank, world)  # round-robin over ranks, like schedule(static,1)
+        for e in range(E):
+            ev = ev_ids[e]
+            for c in range(C):
+                spec = synth.random_spec(W, H, F, ev, c, p_second=0.2)
+                synth.render_event(W, H, spec, ev, c, xp="torch", device=dev, out=slab[e * C + c], bg=bgs[c])
+        # per-camera model from frames 0,1 of the first train-events events (K1 on the GPU)
+        mus, sgs = [], []
         for c in range(C):
-            spec = synth.random_spec(W, H, F, ev, c, p_second=0.2)
-            specs.append(spec)
-            synth.render_event(W, H, spec, ev, c, xp="torch", device=dev, out=slab[e * C + c], bg=bgs[c])
-    # per-camera model from frames 0,1 of the first train-events events (K1 on the GPU)
-    mus, sgs = [], []
-    for c in range(C):
-        idx = torch.tensor([((e * C + c) * F + f) for e in range(min(args.train_events, E)) for f in (0, 1)],
-                           dtype=torch.int32, device=dev)
-        mu, sg = hip.train(slab, W, H, idx=idx)
-        mus.append(mu)
-        sgs.append(sg)
-    mu_d = torch.stack(mus).contiguous()
-    sg_d = torch.stack(sgs).contiguous()
-    s6_d = hip.sigma6(sg_d)
-    torch.cuda.synchronize()
-    gen_s = time.time() - t0
+            idx = torch.tensor([((e * C + c) * F + f) for e in range(min(args.train_events, E)) for f in (0, 1)],
+                               dtype=torch.int32, device=dev)
+            mu, sg = hip.train(slab, W, H, idx=idx)
+            mus.append(mu)
+            sgs.append(sg)
+        mu_d = torch.stack(mus).contiguous()
+        sg_d = torch.stack(sgs).contiguous()
+        s6_d = hip.sigma6(sg_d)
+        torch.cuda.synchronize()
+        gen_s = time.time() - t0
 
-    # ---- the step: end-to-end detect of the whole run (host/pipeline.cpp) -------------------------
-    from autobub3hs_amd import host
+        # ---- the step: end-to-end detect of the whole run (host/pipeline.cpp) -------------------------
+        tss = [2 * min(args.train_events, E)] * C
+        # --inflight N (host.PipelineRing): N pipeline objects, each driven by its own host thread; step k runs on
+        # pipeline k % N, so the host stages of one step (state machines, contours) overlap the GPU stages of the
+        # next.  Every step is still a full pass over the same batch, and all K of them complete inside the block.
+        ninfl = max(1, args.inflight)
+        ring = host.PipelineRing(ninfl, local, W, H, F, E, C, tss, nthreads=max(1, args.threads))
+        pipes = ring.pipes
+        pipe = pipes[0]
+        stream = torch.cuda.current_stream().cuda_stream
 
-    tss = [2 * min(args.train_events, E)] * C
-    # --inflight N (host.PipelineRing): N pipeline objects, each driven by its own host thread; step k runs on pipeline
-    # k % N, so the host stages of one step (state machines, contours) overlap the GPU stages of the next.  Every step
-    # is still a full pass over the same batch, and all K of them complete inside the timed region.
-    ninfl = max(1, args.inflight)
-    ring = host.PipelineRing(ninfl, local, W, H, F, E, C, tss, nthreads=max(1, args.threads))
-    pipes = ring.pipes
-    pipe = pipes[0]
-    stream = torch.cuda.current_stream().cuda_stream
-    njobs = S * (F - 1)
+        def run_steps(n):
+            return ring.run_batches([slab] * n, mu_d, s6_d, stream)
 
-    def run_steps(n):
-        return ring.run_batches([slab] * n, mu_d, s6_d, stream)
+        nwarm = max(args.warmup, ninfl if args.warmup else 0)  # every pipeline object of the ring gets one untimed step
+        run_steps(nwarm)
+        fingerprint = pipe.summary()
 
-    nwarm = max(args.warmup, ninfl if args.warmup else 0)  # every pipeline object of the ring gets one untimed step
-    run_steps(nwarm)
-    fingerprint = pipe.summary()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    stage = {"stage1_ms": 0.0, "stage2_ms": 0.0, "stage3_ms": 0.0, "stage4_ms": 0.0, "total_ms": 0.0, "s3_gpu_ms": 0.0,
-             "s3_list_ms": 0.0, "s3_bucket_ms": 0.0, "pairs": 0.0, "rounds": 0}
-    for tm in run_steps(args.steps):
-        for kk in stage:
-            stage[kk] += tm[kk]
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    dt = shard.max_over_ranks(time.perf_counter() - t1, dev if backend == "nccl" else None)
-    for p_ in pipes[:max(1, min(ninfl, args.steps))]:
-        assert p_.summary() == fingerprint, "results changed between steps"
+    # ---- timed region: blocks of EXACTLY K steps, repeated until --min-seconds are on the clock ---------
+    stage_keys = ("stage1_ms", "stage2_ms", "stage3_ms", "stage4_ms", "total_ms", "s3_gpu_ms", "s3_list_ms",
+                  "s3_bucket_ms", "pairs", "rounds")
+    stage = {k: 0.0 for k in stage_keys}
+    nstage = 0
+    block_s, rank_block_s = [], []
+    total = 0.0
+    while True:
+        dt, own, tms = timed_block(lambda: run_steps(args.steps))
+        rank_block_s.append(own)
+        block_s.append(dt)
+        total += dt
+        for tm in tms:
+            for kk in stage:
+                stage[kk] += tm[kk]
+            nstage += 1
+        # (dt is the max over ranks, so every rank takes the same decision)
+        if total >= args.min_seconds or len(block_s) >= args.max_blocks:
+            break
+    bs = sorted(block_s)
+    med_s = bs[len(bs) // 2] if len(bs) % 2 else 0.5 * (bs[len(bs) // 2 - 1] + bs[len(bs) // 2])
+    my = sorted(rank_block_s)
+    per_rank_ms = gather_floats(my[len(my) // 2] / args.steps * 1e3, world, rank, dist)
+    if not args.dry:
+        for p_ in pipes[:max(1, min(ninfl, args.steps))]:
+            assert p_.summary() == fingerprint, "results changed between steps"
     n_trig = sum(1 for r in fingerprint if r[0] == 0)
     n_bub = sum(r[2] for r in fingerprint)
+
+    frames_per_step = S * F * world
+    out = {
+        "metric": f"frames/s end-to-end detect @{W}x{H} 8-bit",  # BASELINE.json's metric at the default 1280x1024
+        "value": frames_per_step * args.steps / med_s,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": med_s / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {
+            "workload": f"synthetic 40l-19-like run: {E} events x {C} cams x {F} frames {W}x{H} u8 per GPU, HBM-resident; "
+                        "per step: trigger search over every frame, genesis localisation, <=10-frame tracking, per-bubble records",
+            "events_per_gpu": E, "cams": C, "frames_per_stack": F, "width": W, "height": H,
+            "parallelism": f"events dealt round-robin over {world} GPU(s) (event % N), no collective",
+            "host_threads": args.threads,
+            "warmup_steps_run": nwarm,
+            "steps_in_flight": ninfl,  # stage_ms below are wall times inside one step: with >1 in flight they include
+                                       # queueing behind the other steps' kernels and no longer add up to ms_per_step
+            "timing": {"blocks": len(block_s), "steps_per_block": args.steps, "timed_seconds": total,
+                       "ms_per_step_median": med_s / args.steps * 1e3, "ms_per_step_min": bs[0] / args.steps * 1e3,
+                       "ms_per_step_max": bs[-1] / args.steps * 1e3, "ms_per_step_first_block": block_s[0] / args.steps * 1e3,
+                       "ms_per_step_by_rank": per_rank_ms,
+                       "note": "value and ms_per_step are the median K-step block (max over ranks per block)"},
+            "triggered_stacks": n_trig, "bubbles": n_bub,
+            "stage_ms": {k: round(v / max(1, nstage), 3) for k, v in stage.items()},
+            "gen_seconds": round(gen_s, 1),
+        },
+    }
+    if args.dry:
+        out["data"] = "none (dry protocol rehearsal, no kernels)"
+        out["config"]["dry"] = True
+        if rank == 0:
+            print(json.dumps(out))
+        if dist:
+            dist.destroy_process_group()
+        return
+
+    # ---- latency: the same step, one at a time (no overlap between steps) -----------------------------------------
+    if args.latency_steps > 0:
+        lat = []
+        for _ in range(args.latency_steps):
+            torch.cuda.synchronize()
+            tl = time.perf_counter()
+            pipe.run(slab, mu_d, s6_d, stream)
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - tl) * 1e3)
+        lat.sort()
+        out["config"]["latency_one_step_at_a_time_ms"] = {"median": lat[len(lat) // 2], "min": lat[0], "steps": len(lat)}
 
     # ---- PCIe-inclusive rate (reported in config only, never `value`): the same run streamed from pinned host memory
     pcie = None
@@ -157,138 +309,193 @@ def main():
         pcie = {"frames_per_s": S * F / tstream, "ms_per_run": tstream * 1e3,
                 "GBps_host_to_hbm": S * F * P / tstream / 1e9}
         del h_slab
+    out["config"]["pcie_inclusive"] = pcie
 
     # ---- dominant kernel alone, HIP events on the launch stream (roofline object) ---------------
+    njobs = S * (F - 1)
     jobs = hip.stack_jobs(S, F, 1, F - 1, 2, C, dev)
     hist = torch.empty((njobs, 256), dtype=torch.int32, device=dev)
-    kreps = max(3, min(10, args.steps))
+    kreps = max(5, min(20, args.steps))
     chain = (F - 1, 2)  # the pipeline's own call: stack-structured job list, FindTriggerFrame's two-frame offset
-    hip.diff_hist(slab, s6_d, jobs, W, H, store=False, hist=hist, chain=chain)
-    k2_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(kreps)]
-    for a_, b_ in k2_ev:
-        a_.record()
-        hip.diff_hist(slab, s6_d, jobs, W, H, store=False, hist=hist, chain=chain)
-        b_.record()
-    torch.cuda.synchronize()
-    k2_ms = sum(a_.elapsed_time(b_) for a_, b_ in k2_ev) / kreps
-    hist_h = hist.cpu()
 
-    frames_per_step = S * F * world
-    value = frames_per_step * args.steps / dt
-    alg_bytes = 3.0 * P * njobs  # trigger-only mode: read cur, ref, sigma; D not materialised
-    achieved = alg_bytes / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
-    # HBM traffic of this kernel from rocprofv3 PMC passes (tools/prof_k2.sh: FETCH_SIZE x2 + WRITE_SIZE, separate
-    # --pmc runs on the native microbench of the same kernel and frame size), scaled per job; null if not measured
+    def time_launch(fn, reps):
+        fn()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a_, b_ in evs:
+            a_.record()
+            fn()
+            b_.record()
+        torch.cuda.synchronize()
+        ts = sorted(a_.elapsed_time(b_) for a_, b_ in evs)
+        return sum(ts) / len(ts), ts[0]
+
+    k2_ms, k2_min = time_launch(lambda: hip.diff_hist(slab, s6_d, jobs, W, H, store=False, hist=hist, chain=chain), kreps)
+    hist_h = hist.cpu()
+    comp_bytes = 1.0 * P * njobs  # compulsory: every frame of a chain read once (the pass does not write D)
+    alg_bytes = 3.0 * P * njobs   # SURVEY 8(d) accounting: cur, ref and sigma6 charged per job
+    achieved = comp_bytes / (k2_ms * 1e-3) / 1e9
+    # HBM traffic of THIS pass from rocprofv3 --pmc runs wrapping `python3 bench.py` itself (tools/prof_bench_pmc.sh:
+    # FETCH_SIZE x2 + WRITE_SIZE of the pass's kernels, per launch); null if no summary matches this geometry
     traffic, traffic_src = None, None
-    for cand in sorted((os.path.join(ROOT, "profiles", d, "k2_hist_pmc_summary.json")
-                        for d in os.listdir(os.path.join(ROOT, "profiles"))
-                        if os.path.isdir(os.path.join(ROOT, "profiles", d))), reverse=True):
+    prof_root = os.path.join(ROOT, "profiles")
+    for d in sorted((d for d in os.listdir(prof_root) if os.path.isdir(os.path.join(prof_root, d))), reverse=True):
+        cand = os.path.join(prof_root, d, "bench_pmc_summary.json")
         if os.path.exists(cand):
             pm = json.load(open(cand))
-            if pm["micro"]["W"] == W and pm["micro"]["H"] == H:
-                traffic = pm["hbm_bytes_per_job"] * njobs
+            if pm.get("W") == W and pm.get("H") == H and pm.get("jobs_per_launch") == njobs:
+                traffic = pm["hbm_bytes_per_launch"]
                 traffic_src = os.path.relpath(cand, ROOT)
                 break
-
-    out = {
-        "metric": f"frames/s end-to-end detect @{W}x{H} 8-bit",  # BASELINE.json's metric at the default 1280x1024
-        "value": value,
-        "unit": "frames/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "u8",
-        "data": "synthetic",
-        "config": {
-            "workload": f"synthetic 40l-19-like run: {E} events x {C} cams x {F} frames {W}x{H} u8 per GPU, HBM-resident; "
-                        "per step: trigger search over every frame, genesis localisation, <=10-frame tracking, per-bubble records",
-            "events_per_gpu": E, "cams": C, "frames_per_stack": F, "width": W, "height": H,
-            "parallelism": f"events sharded over {world} GPU(s), no collective",
-            "host_threads": args.threads,
-            "warmup_steps_run": nwarm,
-            "steps_in_flight": ninfl,  # stage_ms below are wall times inside one step: with >1 in flight they include
-                                       # queueing behind the other steps' kernels and no longer add up to ms_per_step
-            "triggered_stacks": n_trig, "bubbles": n_bub,
-            "stage_ms": {k: round(v / args.steps, 3) for k, v in stage.items()},
-            "gen_seconds": round(gen_s, 1),
-            "pcie_inclusive": pcie,
-        },
-        "roofline": {
-            "kernel": "K2 trigger-only pass = k2_bound_chain<5,2> (dominant) + k2_exact_groups + k2_rows<5> on handed-over "
-                      "rows + k_hist_bin0, timed together: fused ProcessFrame + 256-bin histogram, 3*W*H B/job",
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
-            "ms_per_launch": k2_ms, "jobs_per_launch": njobs,
-            "note": "frac can exceed 1: the contract's algorithmic accounting charges cur, ref and sigma6 (3*W*H per job) to "
-                    "HBM, but a frame's second use and sigma6 are served on-chip (see traffic: measured HBM bytes per launch)",
-        },
+    out["roofline"] = {
+        "kernel": "K2 trigger-only pass (the pipeline's stage 1) = k2_bound_chain (dominant) + k2_exact_groups + k2_rows on "
+                  "handed-over rows + k_hist_bin0, timed together with HIP events on the launch stream: fused ProcessFrame + "
+                  "256-bin histogram of every frame pair of the run",
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+        "bytes_accounting": "compulsory: 1*W*H per job (each frame of a chain is read from HBM once; D is not written)",
+        "bytes_per_launch": comp_bytes, "ms_per_launch": k2_ms, "ms_per_launch_min": k2_min, "jobs_per_launch": njobs,
+        "frac_of_traffic": (traffic / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+        "contract_algorithmic": {"bytes_per_job": 3 * P, "GBps": alg_bytes / (k2_ms * 1e-3) / 1e9,
+                                 "note": "SURVEY 8(d) figure (cur + ref + sigma6 charged per job); exceeds the peak because "
+                                         "the second use of a frame and sigma6 never reach HBM -- not a roofline fraction"},
     }
 
+    # ---- BASELINE configs[2]: the fused kernel on a contiguous 10k-frame slab, i = 2..F-1, ref = i-2 -------------
+    if args.micro_frames > 4 and rank == 0:
+        out["config"]["microbench"] = microbench(args, torch, hip, dev, W, H)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # CPU baseline = the oracle's whole detect path (AnyCamAnalysis restatement) on a bounded sample
-        # of the same stacks, 1 core.  It doubles as a full-size parity check of the GPU results.
-        from oracle import pyoracle as orc
-
-        orc.build()
-        done, tcpu, nstk = 0, 0.0, 0
-        s_i = 0
-        mu_h = mu_d.cpu().numpy()
-        sg_h = sg_d.cpu().numpy()
-        while tcpu < args.cpu_seconds and s_i < S:
-            st = slab[s_i].cpu().numpy()
-            c = s_i % C
-            tc = time.perf_counter()
-            a = orc.Analyzer(st, mu_h[c], sg_h[c], tss[c])
-            staged_r, state_r, bub_r = a.any_cam_analysis()
-            tcpu += time.perf_counter() - tc
-            a.close()
-            staged, state, bub, err = pipe.result(s_i)
-            same = (staged, state) == (staged_r, state_r) and len(bub) == len(bub_r) and all(
-                [tuple(d[k] for k in "xywh") for d in b["desc"]] == [tuple(d[k] for k in "xywh") for d in r["desc"]]
-                for b, r in zip(bub, bub_r))
-            if not same:
-                raise SystemExit(f"bench.py: GPU result of stack {s_i} differs from the CPU oracle: "
-                                 f"{(staged, state)} vs {(staged_r, state_r)} {err}")
-            # and the trigger-pass histograms of that stack, bit for bit
-            _, hh = orc.bench_trigger_pass(st, sg_h[c], 2, 1, F - 1, want_hists=True)
-            if not np.array_equal(hh, hist_h[s_i * (F - 1):(s_i + 1) * (F - 1)].numpy().astype(np.uint32)):
-                raise SystemExit("bench.py: GPU histograms differ from the CPU oracle on the sampled stack")
-            done += F
-            nstk += 1
-            s_i += max(1, S // 24)
-        # the same oracle, event-parallel over the host cores (the reference's own OpenMP loop is over events,
-        # AutoBubStart3.cpp:342): reported beside the 1-core figure, not instead of it
-        from concurrent.futures import ThreadPoolExecutor
-
-        ncore = max(1, min(len(os.sched_getaffinity(0)), 32, S))
-        stacks_mc = [(slab[s].cpu().numpy(), s % C) for s in range(0, S, max(1, S // ncore))][:ncore]
-
-        def _one(item):
-            st, c = item
-            a = orc.Analyzer(st, mu_h[c], sg_h[c], tss[c])  # ctypes drops the GIL inside the oracle
-            a.any_cam_analysis()
-            a.close()
-
-        with ThreadPoolExecutor(len(stacks_mc)) as ex:
-            tc = time.perf_counter()
-            list(ex.map(_one, stacks_mc))
-            tmc = time.perf_counter() - tc
-        out["cpu_baseline"] = {
-            "value": done / tcpu, "unit": "frames/s", "cores": 1, "kind": "port",
-            "all_cores": {"value": len(stacks_mc) * F / tmc, "cores": len(stacks_mc),
-                          "sample": f"{len(stacks_mc)} stacks at once, one per thread, {tmc:.1f} s"},
-            "sample": f"{nstk} stacks ({done} frames) of the same workload through the oracle's end-to-end detect "
-                      f"(oracle/abub_oracle.c, gcc -O2, results identical to the GPU's), {tcpu:.1f} s on 1 core of {os.cpu_count()}",
-        }
+        out["cpu_baseline"] = cpu_baseline(args, np, torch, slab, mu_d, sg_d, hist_h, pipe, tss, S, F, C)
     if rank == 0:
         print(json.dumps(out))
     if dist:
         dist.destroy_process_group()
+
+
+def microbench(args, torch, hip, dev, W, H):
+    """SURVEY 8(d) "Config 3": slab [N][H][W] in HBM + sigma6, K2 over i = 2..N-1 with ref = i-2, D and [count][256]
+    histograms written (store mode), >= 3 timed repetitions after a warm-up, HIP events on the launch stream."""
+    P = W * H
+    N = args.micro_frames
+    free, _ = torch.cuda.mem_get_info()
+    need = 2 * N * P + (64 << 20)
+    if need > free * 0.9:
+        N = max(64, int((free * 0.9 - (64 << 20)) // (2 * P)))
+    from autobub3hs_amd import synth
+
+    slab = synth.long_stack(N, W, H, xp="torch", device=dev)
+    sg = torch.ones((1, H, W), dtype=torch.uint8, device=dev)
+    s6 = hip.sigma6(sg)
+    njobs = N - 2
+    jobs = hip.make_jobs([(i, i - 2, 0, i - 2) for i in range(2, N)], dev)
+    hist = torch.empty((njobs, 256), dtype=torch.int32, device=dev)
+    D = torch.empty((njobs, H, W), dtype=torch.uint8, device=dev)
+
+    def timeit(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a_, b_ in evs:
+            a_.record()
+            fn()
+            b_.record()
+        torch.cuda.synchronize()
+        ts = sorted(a_.elapsed_time(b_) for a_, b_ in evs)
+        return sum(ts) / len(ts), ts[0]
+
+    res = {"frames": N, "jobs_per_launch": njobs, "width": W, "height": H, "sigma": 1,
+           "data": "synth.long_stack: background + sum of four U{-1,0,1} per pixel and frame (about 3.5 supra-6-sigma noise "
+                   "pixels per row) + a disc of radius <= 33 growing in the second half of every 64-frame block"}
+
+    def row(ms, ms_min, nP):
+        gbps = nP * P * njobs / (ms * 1e-3) / 1e9
+        return {"ms_per_launch": ms, "ms_per_launch_min": ms_min, "us_per_job": ms * 1e3 / njobs,
+                "compulsory_bytes_per_job": nP * P, "compulsory_GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS}
+
+    chain = (njobs, 2)
+    ms, mn = timeit(lambda: hip.diff_hist(slab, s6, jobs, W, H, store=True, hist=hist, diff=D, chain=chain))
+    res["store_mode"] = row(ms, mn, 2)  # read every frame once, write D once
+    h_store = hist.clone()
+    # size-independent checks at full size: totals, bincount(D) == histogram on sampled jobs
+    assert bool((h_store.sum(1) == P).all()), "microbench: histogram totals"
+    for k in range(0, njobs, max(1, njobs // 6)):
+        assert torch.equal(torch.bincount(D[k].flatten().to(torch.int64), minlength=256).to(torch.int32), h_store[k])
+    ms, mn = timeit(lambda: hip.diff_hist(slab, s6, jobs, W, H, store=False, hist=hist, chain=chain))
+    res["trigger_only"] = row(ms, mn, 1)
+    assert torch.equal(hist, h_store), "microbench: trigger-only histograms differ from store mode"
+    # the dense-regime worst case: every row through the full row machine (what a frame of dense foreground costs)
+    hip.k2_set_option("bound", 0)
+    try:
+        ms, mn = timeit(lambda: hip.diff_hist(slab, s6, jobs, W, H, store=True, hist=hist, diff=D), reps=3)
+        res["store_mode_row_machine_only"] = row(ms, mn, 2)
+        assert torch.equal(hist, h_store), "microbench: row-machine histograms differ"
+        ms, mn = timeit(lambda: hip.diff_hist(slab, s6, jobs, W, H, store=False, hist=hist), reps=3)
+        res["trigger_only_row_machine_only"] = row(ms, mn, 1)
+    finally:
+        hip.k2_set_option("bound", 1)
+    res["nonzero_pixels_per_frame"] = float((P - h_store[:, 0].double()).mean().item())
+    res["contract_algorithmic_GBps"] = {"store_mode_4P": 4.0 * P * njobs / (res["store_mode"]["ms_per_launch"] * 1e-3) / 1e9,
+                                        "trigger_only_3P": 3.0 * P * njobs / (res["trigger_only"]["ms_per_launch"] * 1e-3) / 1e9}
+    del slab, D
+    return res
+
+
+def cpu_baseline(args, np, torch, slab, mu_d, sg_d, hist_h, pipe, tss, S, F, C):
+    """CPU baseline = the oracle's whole detect path (AnyCamAnalysis restatement) on a bounded sample of the same
+    stacks, 1 core.  It doubles as a full-size parity check of the GPU results."""
+    from oracle import pyoracle as orc
+
+    orc.build()
+    done, tcpu, nstk = 0, 0.0, 0
+    s_i = 0
+    mu_h = mu_d.cpu().numpy()
+    sg_h = sg_d.cpu().numpy()
+    while tcpu < args.cpu_seconds and s_i < S:
+        st = slab[s_i].cpu().numpy()
+        c = s_i % C
+        tc = time.perf_counter()
+        a = orc.Analyzer(st, mu_h[c], sg_h[c], tss[c])
+        staged_r, state_r, bub_r = a.any_cam_analysis()
+        tcpu += time.perf_counter() - tc
+        a.close()
+        staged, state, bub, err = pipe.result(s_i)
+        same = (staged, state) == (staged_r, state_r) and len(bub) == len(bub_r) and all(
+            [tuple(d[k] for k in "xywh") for d in b["desc"]] == [tuple(d[k] for k in "xywh") for d in r["desc"]]
+            for b, r in zip(bub, bub_r))
+        if not same:
+            raise SystemExit(f"bench.py: GPU result of stack {s_i} differs from the CPU oracle: "
+                             f"{(staged, state)} vs {(staged_r, state_r)} {err}")
+        # and the trigger-pass histograms of that stack, bit for bit
+        _, hh = orc.bench_trigger_pass(st, sg_h[c], 2, 1, F - 1, want_hists=True)
+        if not np.array_equal(hh, hist_h[s_i * (F - 1):(s_i + 1) * (F - 1)].numpy().astype(np.uint32)):
+            raise SystemExit("bench.py: GPU histograms differ from the CPU oracle on the sampled stack")
+        done += F
+        nstk += 1
+        s_i += max(1, S // 24)
+    # the same oracle, event-parallel over the host cores (the reference's own OpenMP loop is over events,
+    # AutoBubStart3.cpp:342): reported beside the 1-core figure, not instead of it
+    from concurrent.futures import ThreadPoolExecutor
+
+    ncore = max(1, min(len(os.sched_getaffinity(0)), 32, S))
+    stacks_mc = [(slab[s].cpu().numpy(), s % C) for s in range(0, S, max(1, S // ncore))][:ncore]
+
+    def _one(item):
+        st, c = item
+        a = orc.Analyzer(st, mu_h[c], sg_h[c], tss[c])  # ctypes drops the GIL inside the oracle
+        a.any_cam_analysis()
+        a.close()
+
+    with ThreadPoolExecutor(len(stacks_mc)) as ex:
+        tc = time.perf_counter()
+        list(ex.map(_one, stacks_mc))
+        tmc = time.perf_counter() - tc
+    return {
+        "value": done / tcpu, "unit": "frames/s", "cores": 1, "kind": "port",
+        "all_cores": {"value": len(stacks_mc) * F / tmc, "cores": len(stacks_mc),
+                      "sample": f"{len(stacks_mc)} stacks at once, one per thread, {tmc:.1f} s"},
+        "sample": f"{nstk} stacks ({done} frames) of the same workload through the oracle's end-to-end detect "
+                  f"(oracle/abub_oracle.c, {orc.CFLAGS_NOTE}, results identical to the GPU's), {tcpu:.1f} s on 1 core of {os.cpu_count()}",
+    }
 
 
 if __name__ == "__main__":

@@ -15,10 +15,12 @@
 #define MIN_IMAGE_SIZE 100000
 
 namespace abub {
-class EventData; // GPU-side view of this analyzer's frame stack (host/devctx.hpp)
+class EventData;       // GPU-side view of this analyzer's frame stack (host/devctx.hpp)
+struct AnalyzerProbe;  // test hook (host/capi.cpp): reaches the private per-frame statistics, dead upstream
 }
 
 class AnalyzerUnit {
+    friend struct abub::AnalyzerProbe;
     int StatusCode = 0;
 
     int minEvalFrameNumber = 2; // frames 0,1 are training frames

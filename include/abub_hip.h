@@ -119,7 +119,21 @@ int abub_fast_path(int W);
 int abub_diff_hist_chained_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs, int njobs, int W,
                                int H, uint32_t *hist, int chain_len, int chain_stride, void *stream);
 
-/* The trigger-only form of abub_diff_hist_dev (diff == NULL) keeps a work list in device scratch memory that the
+/* Store-mode form of the same: D is written too ([nslots][H][W]); the scan writes the rows it proves zero, the listed
+ * groups and the handed-over rows overwrite their pixels.  BASELINE configs[2] (10k-frame slab, i = 2..9999, ref = i-2)
+ * is this call with chain_len = njobs, chain_stride = 2. */
+int abub_diff_hist_chained_store_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs, int njobs, int W,
+                                     int H, uint32_t *hist, uint8_t *diff, int chain_len, int chain_stride, void *stream);
+
+/* Run-time tuning knobs of the K2 launchers (defaults from ABUB_K2_BOUND / _CHAIN / _BUDGET / _PF in the environment):
+ *   "bound"  1 = bound-and-verify pass (default), 0 = the plain row machine for every row (the dense-regime worst case)
+ *   "chain"  jobs per wave of the chained scan: 2 (default) or 3; 0 = never chain
+ *   "budget" suspects a chunk may list before it hands its remaining rows to the row machine
+ *   "pf"     software-prefetch depth of the row machine (1 or 2)
+ * Results never depend on them. */
+int abub_k2_set_option(const char *name, int value);
+
+/* The bound-and-verify form of abub_diff_hist_dev keeps a work list in device scratch memory that the
  * library owns, one buffer per (device, stream), grown on demand.  Call this before destroying a stream that was
  * used for such launches (or at any quiet moment) to give its buffer back; it waits for the stream to drain. */
 int abub_scratch_release(void *stream);

@@ -11,10 +11,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libabub_oracle.so")
+CFLAGS_NOTE = "gcc -O3 -march=x86-64-v3 -ffp-contract=off"  # what oracle/Makefile builds with (quoted by bench.py)
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("abub_oracle.c", "abub_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("abub_oracle.c", "abub_oracle.h", "Makefile")]
     if force or not os.path.exists(_SO) or any(
         os.path.getmtime(s) > os.path.getmtime(_SO) for s in src if os.path.exists(s)
     ):

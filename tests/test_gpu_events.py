@@ -407,3 +407,39 @@ def test_pipeline_ring_batches_in_flight(oracle):
     assert len(tms) == 5 and [got[k] for k in range(5)] == want
     ref = oracle_event(oracle, batches[4][1, 1], models[1][0], models[1][1], 16)
     assert eval(got[4], {"nan": float("nan")})[1 * C + 1][:2] == (ref[0], ref[1])
+
+
+def test_private_frame_statistics_a8(oracle):
+    """SURVEY 8 row a8: AnalyzerUnit::calculateEntropyFrame (128 bins) / calculateEntropySignificance and the image
+    overload of calculateSignificanceFrame (AnalyzerUnit.cpp:386-504) are private and never called upstream; reached
+    here through the abub::AnalyzerProbe friend.  The histogram comes from the GPU (K1b), the statistics from
+    hostlogic; compared with the oracle's orc_entropy128 / orc_significance and a plain restatement of the z-score."""
+    W, H, n = 320, 200, 7
+    rs = np.random.RandomState(8)
+    imgs = np.zeros((n, H, W), np.uint8)
+    for k in range(n):
+        m = rs.rand(H, W) < 0.002 * (k + 1)
+        imgs[k][m] = rs.randint(1, 40 + 30 * k, int(m.sum()))
+    imgs[3, 50:70, 100:130] = rs.randint(0, 256, (20, 30))
+    run = host.Run()
+    run.add_event(5, 0, np.zeros((8, H, W), np.uint8))
+    mu = np.full((H, W), 50, np.uint8)
+    sg = np.ones((H, W), np.uint8)
+    tss = 12
+    run.set_model(0, mu, sg, tss)
+    got = run.probe_frame_stats(5, 0, imgs)
+    a = oracle.Analyzer(np.zeros((8, H, W), np.uint8), mu, sg, tss)
+    hist_e = []
+    for k in range(n):
+        e = np.float32(oracle.entropy128(imgs[k]))
+        assert np.float32(got[k, 0]) == e, k
+        hist_e.append(float(e))
+        mean = sum(hist_e) / len(hist_e)              # CalcMean / CalcStdDev<double> (AnalyzerUnit.cpp:514-532)
+        sd = np.sqrt(np.float64(sum(v * v for v in hist_e)) / len(hist_e) - mean * mean)
+        with np.errstate(all="ignore"):
+            z = (np.float64(e) - mean) / sd
+        assert (np.isnan(z) and np.isnan(got[k, 1])) or z == got[k, 1] or abs(z - got[k, 1]) <= 1e-9 * abs(z), (k, z, got[k, 1])
+        s = a.significance(oracle.hist256(imgs[k]), True)
+        assert (np.isnan(s) and np.isnan(got[k, 2])) or s == got[k, 2], (k, s, got[k, 2])
+    a.close()
+    run.close()

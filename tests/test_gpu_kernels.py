@@ -11,6 +11,15 @@ from autobub3hs_amd import hip, synth  # noqa: E402
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _k2_defaults():
+    """Every test starts from (and leaves behind) the default K2 launcher options."""
+    yield
+    hip.k2_set_option("bound", 1)
+    hip.k2_set_option("chain", 2)
+    hip.k2_set_option("budget", 1024)
+
+
 def rnd_frames(rs, n, H, W, base=None, amp=12):
     if base is None:
         base = rs.randint(30, 200, (H, W))
@@ -46,12 +55,17 @@ def test_k2_diff_hist_parity(oracle, H, W, R):
     s6 = hip.sigma6(torch.from_numpy(sigma).to(DEV))
     assert np.array_equal(s6.cpu().numpy(), np.minimum(6 * sigma.astype(int), 255).astype(np.uint8))
     j_d = hip.make_jobs(jobs, DEV)
-    for store in (True, False):
-        hist, diff = hip.diff_hist(f_d, s6, j_d, W, H, store=store, rows_per_chunk=R)
-        torch.cuda.synchronize()
-        assert np.array_equal(hist.cpu().numpy().astype(np.uint32), href), (H, W, store)
-        if store:
-            assert np.array_equal(diff.cpu().numpy(), Dref)
+    # bound = 1: bound-and-verify pass (scan + exact groups + handed-over rows), bound = 0: the row machine alone;
+    # budget 8 forces hand-overs in the middle of chunks
+    for bound, budget in ((1, 1024), (0, 1024), (1, 8)):
+        hip.k2_set_option("bound", bound)
+        hip.k2_set_option("budget", budget)
+        for store in (True, False):
+            hist, diff = hip.diff_hist(f_d, s6, j_d, W, H, store=store, rows_per_chunk=R)
+            torch.cuda.synchronize()
+            assert np.array_equal(hist.cpu().numpy().astype(np.uint32), href), (H, W, store, bound, budget)
+            if store:
+                assert np.array_equal(diff.cpu().numpy(), Dref), (H, W, bound, budget)
 
 
 def test_k2_extreme_values(oracle):
@@ -105,6 +119,13 @@ def test_k2_trigger_only_bound_and_verify(oracle, H, W, R):
     s6 = hip.sigma6(torch.from_numpy(sigma).to(DEV))
     hist, _ = hip.diff_hist(f_d, s6, hip.make_jobs(jobs, DEV), W, H, store=False, rows_per_chunk=R)
     assert np.array_equal(hist.cpu().numpy().astype(np.uint32), href)
+    # store mode of the same pass: the scan writes the zero rows, the exact groups their pixels
+    Dref, _ = oracle_hists(oracle, frames, sigma, jobs)
+    for budget in (1024, 16):
+        hip.k2_set_option("budget", budget)
+        hist, D = hip.diff_hist(f_d, s6, hip.make_jobs(jobs, DEV), W, H, store=True, rows_per_chunk=R)
+        assert np.array_equal(hist.cpu().numpy().astype(np.uint32), href)
+        assert np.array_equal(D.cpu().numpy(), Dref), budget
 
 
 def test_k2_stack_jobs_and_synthetic_event(oracle):
@@ -297,9 +318,16 @@ def test_k2_trigger_only_equals_store_mode_full_size(W, H):
     s6 = hip.sigma6(sg)
     jobs = hip.stack_jobs(1, F, 1, F - 1, 2, 1, DEV)
     h_trig, _ = hip.diff_hist(fr, s6, jobs, W, H, store=False)
-    h_store, D = hip.diff_hist(fr, s6, jobs, W, H, store=True)
+    h_bstore, D_b = hip.diff_hist(fr, s6, jobs, W, H, store=True)  # bound-and-verify, store mode
+    h_cstore, D_c = hip.diff_hist(fr, s6, jobs, W, H, store=True, chain=(F - 1, 2))  # chained scan, store mode
+    hip.k2_set_option("chain", 3)
+    h_c3, D_c3 = hip.diff_hist(fr, s6, jobs, W, H, store=True, chain=(F - 1, 2))
+    hip.k2_set_option("bound", 0)
+    h_store, D = hip.diff_hist(fr, s6, jobs, W, H, store=True)  # the row machine alone
     torch.cuda.synchronize()
-    assert torch.equal(h_trig, h_store)
+    assert torch.equal(h_trig, h_store) and torch.equal(h_bstore, h_store) and torch.equal(h_cstore, h_store)
+    assert torch.equal(h_c3, h_store)
+    assert torch.equal(D_b, D) and torch.equal(D_c, D) and torch.equal(D_c3, D)
     for k in (0, 5, 12, 19, 21, 22):
         assert torch.equal(torch.bincount(D[k].flatten().to(torch.int64), minlength=256).to(h_store.dtype), h_store[k])
     assert int(h_store[19, 1:].sum()) > W * H // 2  # the dense frame really is dense
@@ -331,11 +359,17 @@ def test_k2_chained_trigger_pass(oracle, W, H, F, off):
     jn = jobs.cpu().numpy()
     _, href = oracle_hists(oracle, frames, sigma, [tuple(r) for r in jn])
     assert np.array_equal(plain.cpu().numpy().astype(np.uint32), href)
-    for L, S in [(F - 1, off), (F - 1, off + 1), (F - 1, 1), ((F - 1) * nst, off), (1, 1)]:
-        if ((F - 1) * nst) % L:
-            continue
-        got, _ = hip.diff_hist(f_d, s6, jobs, W, H, chain=(L, S))
-        assert torch.equal(got, plain), (L, S)
+    Dref, _ = oracle_hists(oracle, frames, sigma, [tuple(r) for r in jn])
+    for K in (2, 3):
+        hip.k2_set_option("chain", K)
+        for L, S in [(F - 1, off), (F - 1, off + 1), (F - 1, 1), ((F - 1) * nst, off), (1, 1)]:
+            if ((F - 1) * nst) % L:
+                continue
+            got, _ = hip.diff_hist(f_d, s6, jobs, W, H, chain=(L, S))
+            assert torch.equal(got, plain), (K, L, S)
+            got, D = hip.diff_hist(f_d, s6, jobs, W, H, chain=(L, S), store=True)
+            assert torch.equal(got, plain), (K, L, S)
+            assert np.array_equal(D.cpu().numpy(), Dref), (K, L, S)
 
 
 def test_scratch_release_and_reuse():

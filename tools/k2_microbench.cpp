@@ -1,7 +1,8 @@
 // k2_microbench -- native driver of the fused ProcessFrame(+hist) kernel on a contiguous synthetic slab
 // (BASELINE.json configs[2]: "Synthetic 10k-frame stack 1280x1024, fused diff+thresh+morph HBM-roofline
 // microbench").  Exists so that rocprofv3 --pmc can wrap a plain native program.
-//   k2_microbench [frames=2000] [reps=5] [store=0|1] [W=1280] [H=1024] [rows_per_chunk=0]
+//   k2_microbench [frames=2000] [reps=5] [store=0|1] [W=1280] [H=1024] [rows_per_chunk=0] [sigma=1] [chain=1]
+// (ABUB_K2_BOUND=0 in the environment: the plain row machine for every row, the dense-regime worst case)
 // Build: hipcc --offload-arch=gfx950 -O2 tools/k2_microbench.cpp -Iinclude -Lautobub3hs_amd -labub_hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -68,12 +69,12 @@ int main(int argc, char **argv)
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
     CK(hipEventCreate(&b));
-    if (chain && !store && !R) AK(abub_diff_hist_chained_dev(slab, sigma6, jobs, njobs, W, H, hist, njobs, 2, nullptr)); else AK(abub_diff_hist_dev(slab, sigma6, jobs, njobs, W, H, hist, diff, R, nullptr)); // warm-up
+    if (chain && !R && store) AK(abub_diff_hist_chained_store_dev(slab, sigma6, jobs, njobs, W, H, hist, diff, njobs, 2, nullptr)); else if (chain && !R) AK(abub_diff_hist_chained_dev(slab, sigma6, jobs, njobs, W, H, hist, njobs, 2, nullptr)); else AK(abub_diff_hist_dev(slab, sigma6, jobs, njobs, W, H, hist, diff, R, nullptr)); // warm-up
     CK(hipDeviceSynchronize());
     float best = 1e30f, sum = 0;
     for (int r = 0; r < reps; r++) {
         CK(hipEventRecord(a, 0));
-        if (chain && !store && !R) AK(abub_diff_hist_chained_dev(slab, sigma6, jobs, njobs, W, H, hist, njobs, 2, nullptr)); else AK(abub_diff_hist_dev(slab, sigma6, jobs, njobs, W, H, hist, diff, R, nullptr));
+        if (chain && !R && store) AK(abub_diff_hist_chained_store_dev(slab, sigma6, jobs, njobs, W, H, hist, diff, njobs, 2, nullptr)); else if (chain && !R) AK(abub_diff_hist_chained_dev(slab, sigma6, jobs, njobs, W, H, hist, njobs, 2, nullptr)); else AK(abub_diff_hist_dev(slab, sigma6, jobs, njobs, W, H, hist, diff, R, nullptr));
         CK(hipEventRecord(b, 0));
         CK(hipEventSynchronize(b));
         float ms;
@@ -92,10 +93,12 @@ int main(int argc, char **argv)
                 nz += hh[(size_t)j * 256 + k];
         }
     double ms = sum / reps;
-    double bytes = (store ? 4.0 : 3.0) * P * njobs;
-    printf("{\"frames\": %d, \"W\": %d, \"H\": %d, \"store\": %d, \"ms_avg\": %.4f, \"ms_min\": %.4f, "
-           "\"frames_per_s\": %.1f, \"alg_GBps\": %.1f, \"frac_of_8TBps\": %.4f, \"nonzero_px\": %llu, \"hist_total_ok\": %d}\n",
-           njobs, W, H, store, ms, best, njobs / (ms * 1e-3), bytes / (ms * 1e-3) / 1e9,
-           bytes / (ms * 1e-3) / 1e9 / 8000.0, nz, tot == (unsigned long long)P * njobs);
+    // compulsory bytes: every frame once (+ D once in store mode); the contract's algorithmic figure charges cur, ref, sigma6
+    double bytes = (store ? 4.0 : 3.0) * P * njobs, comp = (store ? 2.0 : 1.0) * P * njobs;
+    printf("{\"frames\": %d, \"W\": %d, \"H\": %d, \"store\": %d, \"chain\": %d, \"sigma\": %d, \"ms_avg\": %.4f, \"ms_min\": %.4f, "
+           "\"frames_per_s\": %.1f, \"compulsory_GBps\": %.1f, \"frac_of_8TBps\": %.4f, \"alg_GBps\": %.1f, \"nonzero_px\": %llu, "
+           "\"hist_total_ok\": %d}\n",
+           njobs, W, H, store, chain, sig, ms, best, njobs / (ms * 1e-3), comp / (ms * 1e-3) / 1e9, comp / (ms * 1e-3) / 1e9 / 8000.0,
+           bytes / (ms * 1e-3) / 1e9, nz, tot == (unsigned long long)P * njobs);
     return 0;
 }

@@ -1,0 +1,294 @@
+// rowload_bench -- how fast the memory system feeds one-wave-per-row-chunk kernels under different lane->byte
+// mappings of a row, with the arithmetic removed (rows are only OR-ed together).  Decides the lane mapping of K2/K3.
+//   MAP 0  blocked: lane L owns bytes [4*NDW*L, 4*NDW*(L+1))  (round-1 mapping: dwordx4 + dword at a 20-byte stride)
+//   MAP 1  split:   segment A = dwordx4 at 16*L, then dwordx2 / dword segments for the rest of the row (every
+//                   load instruction covers one contiguous span of the row)
+//   MAP 2  dwords:  NDW dword loads at 4*(L + 64*k)
+// Patterns: single = 3 row streams per job (cur, ref, sigma6); chain2 = one wave serves 2 jobs sharing a frame
+// (3 frames + sigma6 per step); chain2+store = the same plus two zero rows stored per step (store mode).
+// Build: hipcc --offload-arch=gfx950 -O3 tools/rowload_bench.cpp -o tools/rowload_bench
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+template <int W, int MAP>
+struct RowMap;
+
+// ---- W = 1280 -------------------------------------------------------------------------------------------------
+template <>
+struct RowMap<1280, 0> {
+    static constexpr int N = 5;
+    static __device__ __forceinline__ void load(uint32_t (&r)[N], const uint8_t *row, int lane)
+    {
+        const uint32_t *p = (const uint32_t *)(row + 20 * lane);
+#pragma unroll
+        for (int d = 0; d < 5; d++) r[d] = p[d];
+    }
+    static __device__ __forceinline__ void store0(uint8_t *row, int lane)
+    {
+        uint32_t *p = (uint32_t *)(row + 20 * lane);
+#pragma unroll
+        for (int d = 0; d < 5; d++) p[d] = 0;
+    }
+    static __device__ __forceinline__ void store0nt(uint8_t *row, int lane)
+    {
+        uint32_t *p = (uint32_t *)(row + 20 * lane);
+#pragma unroll
+        for (int d = 0; d < 5; d++) __builtin_nontemporal_store(0u, &p[d]);
+    }
+};
+template <>
+struct RowMap<1280, 1> {
+    static constexpr int N = 5;
+    static __device__ __forceinline__ void load(uint32_t (&r)[N], const uint8_t *row, int lane)
+    {
+        const uint4 a = *(const uint4 *)(row + 16 * lane);
+        r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+        r[4] = *(const uint32_t *)(row + 1024 + 4 * lane);
+    }
+    static __device__ __forceinline__ void store0(uint8_t *row, int lane)
+    {
+        *(uint4 *)(row + 16 * lane) = make_uint4(0, 0, 0, 0);
+        *(uint32_t *)(row + 1024 + 4 * lane) = 0;
+    }
+    static __device__ __forceinline__ void store0nt(uint8_t *row, int lane)
+    {
+        { uint4 *q_ = (uint4 *)(row + 16 * lane); __builtin_nontemporal_store(0u, &q_->x); __builtin_nontemporal_store(0u, &q_->y); __builtin_nontemporal_store(0u, &q_->z); __builtin_nontemporal_store(0u, &q_->w); }
+        __builtin_nontemporal_store(0u, (uint32_t *)(row + 1024 + 4 * lane));
+    }
+};
+template <>
+struct RowMap<1280, 2> {
+    static constexpr int N = 5;
+    static __device__ __forceinline__ void load(uint32_t (&r)[N], const uint8_t *row, int lane)
+    {
+#pragma unroll
+        for (int d = 0; d < 5; d++) r[d] = *(const uint32_t *)(row + 256 * d + 4 * lane);
+    }
+    static __device__ __forceinline__ void store0(uint8_t *row, int lane)
+    {
+#pragma unroll
+        for (int d = 0; d < 5; d++) *(uint32_t *)(row + 256 * d + 4 * lane) = 0;
+    }
+    static __device__ __forceinline__ void store0nt(uint8_t *row, int lane)
+    {
+#pragma unroll
+        for (int d = 0; d < 5; d++) __builtin_nontemporal_store(0u, (uint32_t *)(row + 256 * d + 4 * lane));
+    }
+};
+// ---- W = 1680 -------------------------------------------------------------------------------------------------
+template <>
+struct RowMap<1680, 0> { // 60 lanes x 28 bytes
+    static constexpr int N = 7;
+    static __device__ __forceinline__ void load(uint32_t (&r)[N], const uint8_t *row, int lane)
+    {
+        const int l = lane < 60 ? lane : 0;
+        const uint32_t *p = (const uint32_t *)(row + 28 * l);
+#pragma unroll
+        for (int d = 0; d < 7; d++) r[d] = p[d];
+    }
+    static __device__ __forceinline__ void store0(uint8_t *row, int lane)
+    {
+        if (lane < 60) {
+            uint32_t *p = (uint32_t *)(row + 28 * lane);
+#pragma unroll
+            for (int d = 0; d < 7; d++) p[d] = 0;
+        }
+    }
+    static __device__ __forceinline__ void store0nt(uint8_t *row, int lane)
+    {
+        if (lane < 60) {
+            uint32_t *p = (uint32_t *)(row + 28 * lane);
+#pragma unroll
+            for (int d = 0; d < 7; d++) __builtin_nontemporal_store(0u, &p[d]);
+        }
+    }
+};
+template <>
+struct RowMap<1680, 1> { // 64 x 16 + 64 x 8 + 36 x 4
+    static constexpr int N = 7;
+    static __device__ __forceinline__ void load(uint32_t (&r)[N], const uint8_t *row, int lane)
+    {
+        const uint4 a = *(const uint4 *)(row + 16 * lane);
+        r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+        const uint2 b = *(const uint2 *)(row + 1024 + 8 * lane);
+        r[4] = b.x; r[5] = b.y;
+        const int l = lane < 36 ? lane : 0;
+        r[6] = *(const uint32_t *)(row + 1536 + 4 * l);
+    }
+    static __device__ __forceinline__ void store0(uint8_t *row, int lane)
+    {
+        *(uint4 *)(row + 16 * lane) = make_uint4(0, 0, 0, 0);
+        *(uint2 *)(row + 1024 + 8 * lane) = make_uint2(0, 0);
+        if (lane < 36) *(uint32_t *)(row + 1536 + 4 * lane) = 0;
+    }
+    static __device__ __forceinline__ void store0nt(uint8_t *row, int lane)
+    {
+        { uint4 *q_ = (uint4 *)(row + 16 * lane); __builtin_nontemporal_store(0u, &q_->x); __builtin_nontemporal_store(0u, &q_->y); __builtin_nontemporal_store(0u, &q_->z); __builtin_nontemporal_store(0u, &q_->w); }
+        { uint2 *q_ = (uint2 *)(row + 1024 + 8 * lane); __builtin_nontemporal_store(0u, &q_->x); __builtin_nontemporal_store(0u, &q_->y); }
+        if (lane < 36) __builtin_nontemporal_store(0u, (uint32_t *)(row + 1536 + 4 * lane));
+    }
+};
+template <>
+struct RowMap<1680, 2> { // 64 x 16 + 41 x 16
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(uint32_t (&r)[N], const uint8_t *row, int lane)
+    {
+        const uint4 a = *(const uint4 *)(row + 16 * lane);
+        r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+        const int l = lane < 41 ? lane : 0;
+        const uint4 b = *(const uint4 *)(row + 1024 + 16 * l);
+        r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+    }
+    static __device__ __forceinline__ void store0(uint8_t *row, int lane)
+    {
+        *(uint4 *)(row + 16 * lane) = make_uint4(0, 0, 0, 0);
+        if (lane < 41) *(uint4 *)(row + 1024 + 16 * lane) = make_uint4(0, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void store0nt(uint8_t *row, int lane)
+    {
+        { uint4 *q_ = (uint4 *)(row + 16 * lane); __builtin_nontemporal_store(0u, &q_->x); __builtin_nontemporal_store(0u, &q_->y); __builtin_nontemporal_store(0u, &q_->z); __builtin_nontemporal_store(0u, &q_->w); }
+        if (lane < 41) { uint4 *q_ = (uint4 *)(row + 1024 + 16 * lane); __builtin_nontemporal_store(0u, &q_->x); __builtin_nontemporal_store(0u, &q_->y); __builtin_nontemporal_store(0u, &q_->z); __builtin_nontemporal_store(0u, &q_->w); }
+    }
+};
+
+// single: job j reads frames j+2 (cur), j (ref) and sigma6
+template <int W, int MAP>
+__global__ __launch_bounds__(64) void rd_single(const uint8_t *__restrict__ frames, const uint8_t *__restrict__ sg, int H, int R,
+                                                int nchunks, uint32_t *out)
+{
+    using M = RowMap<W, MAP>;
+    const int lane = threadIdx.x, unit = blockIdx.x, job = unit / nchunks, chunk = unit - job * nchunks;
+    const size_t P = (size_t)W * H;
+    const uint8_t *cur = frames + (size_t)(job + 2) * P, *ref = frames + (size_t)job * P;
+    const int y0 = chunk * R;
+    int y1 = y0 + R; if (y1 > H) y1 = H;
+    uint32_t acc = 0;
+    uint32_t buf[2][3][M::N];
+    auto load = [&](int slot, int y) {
+        const size_t o = (size_t)(y < H ? y : H - 1) * W;
+        M::load(buf[slot][0], cur + o, lane); M::load(buf[slot][1], ref + o, lane); M::load(buf[slot][2], sg + o, lane);
+    };
+    load(0, y0);
+    for (int y = y0; y < y1; y += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            load(u ^ 1, y + u + 1);
+#pragma unroll
+            for (int d = 0; d < M::N; d++) acc |= buf[u][0][d] ^ buf[u][1][d] ^ buf[u][2][d];
+        }
+    }
+    if (acc == 0x12345678u) out[unit] = acc;
+}
+
+// chain of K jobs per wave: frames base, base+2, .., base+2K (+ sigma6); STORE: K zero rows stored per step
+template <int W, int MAP, int K, int STORE>
+__global__ __launch_bounds__(64) void rd_chain(const uint8_t *__restrict__ frames, const uint8_t *__restrict__ sg, int H, int R,
+                                               int nchunks, uint32_t *out, uint8_t *__restrict__ diff)
+{
+    using M = RowMap<W, MAP>;
+    const int lane = threadIdx.x, unit = blockIdx.x, ch = unit / nchunks, chunk = unit - ch * nchunks;
+    const size_t P = (size_t)W * H;
+    const int base = (ch / 2) * 2 * K + (ch & 1); // first job of the chain
+    const int y0 = chunk * R;
+    int y1 = y0 + R; if (y1 > H) y1 = H;
+    uint32_t acc = 0;
+    uint32_t buf[2][K + 2][M::N];
+    auto load = [&](int slot, int y) {
+        const size_t o = (size_t)(y < H ? y : H - 1) * W;
+#pragma unroll
+        for (int f = 0; f <= K; f++) M::load(buf[slot][f], frames + (size_t)(base + 2 * f) * P + o, lane);
+        M::load(buf[slot][K + 1], sg + o, lane);
+    };
+    load(0, y0);
+    for (int y = y0; y < y1; y += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            load(u ^ 1, y + u + 1);
+#pragma unroll
+            for (int f = 0; f < K + 2; f++)
+#pragma unroll
+                for (int d = 0; d < M::N; d++) acc |= buf[u][f][d] + (uint32_t)f;
+            if (STORE && y + u < y1) {
+#pragma unroll
+                for (int f = 0; f < K; f++) {
+                    uint8_t *row = diff + (size_t)(base + 2 * f) * P + (size_t)(y + u) * W;
+                    if (STORE == 2) M::store0nt(row, lane); else M::store0(row, lane);
+                }
+            }
+        }
+    }
+    if (acc == 0x12345678u) out[unit] = acc;
+}
+
+static hipEvent_t e0, e1;
+template <typename F>
+static float timeit(F launch, int reps)
+{
+    launch();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; i++) launch();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+
+template <int W, int MAP>
+static void run(const uint8_t *slab, const uint8_t *sg, uint32_t *out, uint8_t *diff, int F, int H, int R)
+{
+    if (R <= 0) R = (H + 7) / 8; // 8 chunks per frame: chunk id == XCD id, like the kernels' default
+    const int njobs = F - 2, nch = (H + R - 1) / R, reps = 5;
+    const double P = (double)W * H;
+    float ms = timeit([&] { hipLaunchKernelGGL((rd_single<W, MAP>), dim3(njobs * nch), dim3(64), 0, 0, slab, sg, H, R, nch, out); }, reps);
+    printf("{\"W\": %d, \"map\": %d, \"pattern\": \"single\", \"jobs\": %d, \"ms\": %.4f, \"us_per_job\": %.4f, \"compulsory_TBps\": %.3f}\n", W, MAP,
+           njobs, ms, 1e3 * ms / njobs, P * njobs / ms / 1e9);
+    const int nchains = (njobs / 4) * 2;
+    ms = timeit([&] { hipLaunchKernelGGL((rd_chain<W, MAP, 2, 0>), dim3(nchains * nch), dim3(64), 0, 0, slab, sg, H, R, nch, out, diff); }, reps);
+    printf("{\"W\": %d, \"map\": %d, \"pattern\": \"chain2\", \"jobs\": %d, \"ms\": %.4f, \"us_per_job\": %.4f, \"compulsory_TBps\": %.3f}\n", W, MAP,
+           nchains * 2, ms, 1e3 * ms / (nchains * 2), P * nchains * 2 / ms / 1e9);
+    ms = timeit([&] { hipLaunchKernelGGL((rd_chain<W, MAP, 2, 1>), dim3(nchains * nch), dim3(64), 0, 0, slab, sg, H, R, nch, out, diff); }, reps);
+    printf("{\"W\": %d, \"map\": %d, \"pattern\": \"chain2+store\", \"jobs\": %d, \"ms\": %.4f, \"us_per_job\": %.4f, \"compulsory_TBps\": %.3f}\n", W,
+           MAP, nchains * 2, ms, 1e3 * ms / (nchains * 2), 2 * P * nchains * 2 / ms / 1e9);
+    ms = timeit([&] { hipLaunchKernelGGL((rd_chain<W, MAP, 2, 2>), dim3(nchains * nch), dim3(64), 0, 0, slab, sg, H, R, nch, out, diff); }, reps);
+    printf("{\"W\": %d, \"map\": %d, \"pattern\": \"chain2+ntstore\", \"jobs\": %d, \"ms\": %.4f, \"us_per_job\": %.4f, \"compulsory_TBps\": %.3f}\n", W,
+           MAP, nchains * 2, ms, 1e3 * ms / (nchains * 2), 2 * P * nchains * 2 / ms / 1e9);
+    const int nchains3 = (njobs / 6) * 2;
+    ms = timeit([&] { hipLaunchKernelGGL((rd_chain<W, MAP, 3, 0>), dim3(nchains3 * nch), dim3(64), 0, 0, slab, sg, H, R, nch, out, diff); }, reps);
+    printf("{\"W\": %d, \"map\": %d, \"pattern\": \"chain3\", \"jobs\": %d, \"ms\": %.4f, \"us_per_job\": %.4f, \"compulsory_TBps\": %.3f}\n", W, MAP,
+           nchains3 * 3, ms, 1e3 * ms / (nchains3 * 3), P * nchains3 * 3 / ms / 1e9);
+    ms = timeit([&] { hipLaunchKernelGGL((rd_chain<W, MAP, 3, 1>), dim3(nchains3 * nch), dim3(64), 0, 0, slab, sg, H, R, nch, out, diff); }, reps);
+    printf("{\"W\": %d, \"map\": %d, \"pattern\": \"chain3+store\", \"jobs\": %d, \"ms\": %.4f, \"us_per_job\": %.4f, \"compulsory_TBps\": %.3f}\n", W, MAP,
+           nchains3 * 3, ms, 1e3 * ms / (nchains3 * 3), 2 * P * nchains3 * 3 / ms / 1e9);
+    const int nchains4 = (njobs / 8) * 2;
+    ms = timeit([&] { hipLaunchKernelGGL((rd_chain<W, MAP, 4, 0>), dim3(nchains4 * nch), dim3(64), 0, 0, slab, sg, H, R, nch, out, diff); }, reps);
+    printf("{\"W\": %d, \"map\": %d, \"pattern\": \"chain4\", \"jobs\": %d, \"ms\": %.4f, \"us_per_job\": %.4f, \"compulsory_TBps\": %.3f}\n", W, MAP,
+           nchains4 * 4, ms, 1e3 * ms / (nchains4 * 4), P * nchains4 * 4 / ms / 1e9);
+}
+
+int main(int argc, char **argv)
+{
+    const int F = argc > 1 ? atoi(argv[1]) : 2000, R = argc > 2 ? atoi(argv[2]) : 0;
+    const size_t Pmax = (size_t)1680 * 1050;
+    uint8_t *slab, *sg, *diff;
+    uint32_t *out;
+    CK(hipMalloc(&slab, Pmax * F));
+    CK(hipMalloc(&diff, Pmax * F));
+    CK(hipMalloc(&sg, Pmax));
+    CK(hipMalloc(&out, 4 * (size_t)F * 16));
+    CK(hipMemset(slab, 1, Pmax * F));
+    CK(hipMemset(sg, 2, Pmax));
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    run<1280, 0>(slab, sg, out, diff, F, 1024, R);
+    run<1280, 1>(slab, sg, out, diff, F, 1024, R);
+    run<1280, 2>(slab, sg, out, diff, F, 1024, R);
+    run<1680, 0>(slab, sg, out, diff, F, 1050, R);
+    run<1680, 1>(slab, sg, out, diff, F, 1050, R);
+    run<1680, 2>(slab, sg, out, diff, F, 1050, R);
+    return 0;
+}
