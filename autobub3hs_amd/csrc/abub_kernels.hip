@@ -490,8 +490,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER
     const bool last_lane = lane == nl - 1;
     const int xoff = active ? lane * 4 * NDW : 0; // idle lanes shadow lane 0 (results unused)
 
-    const int y0 = unit_list ? (int)unit_list[ui].y : chunk * rows_per_chunk; // list mode: the rows left over
-    int y1 = (chunk + 1) * rows_per_chunk;
+    // list mode: a handed-over piece, rows [y & 0xffff, y >> 16)
+    const int y0 = unit_list ? (int)(unit_list[ui].y & 0xffffu) : chunk * rows_per_chunk;
+    int y1 = unit_list ? (int)(unit_list[ui].y >> 16) : (chunk + 1) * rows_per_chunk;
     if (y1 > H)
         y1 = H;
     const int T = y1 - y0 + 4; // input rows y0-2 .. y1+1 (reflected)
@@ -561,27 +562,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2 trigger-only, "bound and verify".  The trigger search only needs the histogram of D, and D(y,x) != 0 needs a
-// 5x5 weighted sum S >= 128 in one plane.  With X = pos + neg (disjoint supports, so both plane sums are <= the sum
-// over X) and the lane's pixels in groups of four columns:
+// K2 "bound and verify".  D(y,x) != 0 needs a 5x5 weighted sum S >= 128 in one plane.  With X = pos + neg (disjoint
+// supports, so both plane sums are <= the sum over X) and the lane's pixels in groups of four columns:
 //     S(y,x) <= sum_i w_i * 6 * M_g(y+i),   M_g(r) = m_{g-1}(r) + m_g(r) + m_{g+1}(r),   m_g = mass of X in group g
 // (every tap of the horizontal filter is <= 6 and reaches at most the neighbouring group; at the image edges the
 // reflected columns fall into the edge group itself, which the edge-replicated m_{-1} = m_0 counts a second time).
-//   k2_bound_scan   one wave per (job, chunk) carries only this bound down the rows -- the same 1-4-6-4-1 recurrence,
-//                   but on NDW packed group masses per lane instead of 4*NDW filtered pairs in two planes (70 VGPRs,
-//                   7 waves/SIMD: the pass runs at what the memory system can feed) -- and proves "D is zero" for
-//                   whole rows with one ballot.  Groups it cannot prove go to a list (LDS first, one global
-//                   reservation per chunk); a chunk with more than K2B_PEND of them (a big bubble, or dense
-//                   foreground) is handed over whole instead.
-//   k2_exact_groups one lane per listed (job, row, group): the four pixels of D exactly, from their 5 x 8 inputs.
-//   k2_rows (list)  the full row machine on the chunks handed over whole.
-// Every pixel is either proven zero or computed with the reference arithmetic, and never twice (a chunk that is
-// handed over drops its pending groups): the histogram is bit-identical to the plain k2_rows pass.
+//   k2_bound_scan / k2_bound_chain
+//       one wave per (job, chunk) -- or per K chained jobs -- carries only this bound down the rows: the same
+//       1-4-6-4-1 recurrence, but on packed group masses instead of 4*NDW filtered pairs in two planes, and proves
+//       "D is zero" for whole rows with one ballot.  Groups it cannot prove are remembered in LDS (at most K2B_PEND
+//       per job and chunk) and computed exactly BY THE SAME WAVE once its scan is over (k2b_tail: the four pixels
+//       straight from the definition, one lane per group) -- no list in global memory, no second kernel.  A chunk
+//       whose rows keep exceeding 32 suspects (one row of the row machine costs about 30 exact groups), or that
+//       would overflow its LDS list, hands its REMAINING rows over.
+//   k2_rows (list mode)
+//       the full row machine on the handed-over row ranges, cut into pieces of K2B_SUB rows so that the few of them
+//       spread over the chip instead of serialising behind one wave each.
+// Store mode: the scan writes the rows it is responsible for as zeros, the tail overwrites its groups' dwords (same
+// wave, later in program order), the row machine writes the handed-over rows.
+// Every pixel is either proven zero or computed with the reference arithmetic, never twice: histograms and D are
+// bit-identical to the plain k2_rows pass.
 // Packed halves: a register holds (mass of columns 0,2 | mass of columns 1,3) of a group; all recurrences are linear
-// and stay < 65536 per half (<= 16 * 4 * 2 * 255 with paired groups); the row test folds max-of-halves over the lane's groups, which
-// can only over-estimate, the per-group test on a suspicious row folds exactly.
+// and stay < 65536 per half (<= 16 * 4 * 2 * 255 with paired groups); the row test folds max-of-halves over the
+// lane's groups, which can only over-estimate, the per-group test on a suspicious row folds exactly.
 // ------------------------------------------------------------------------------------------------
-#define K2B_PEND 512 /* >= the groups of one row (W/4 <= 512) */
+#define K2B_PEND 512 /* suspects per (job, chunk) kept in LDS; also >= the groups of one row (W/4 <= 512) */
+#define K2B_SUB 32   /* rows per handed-over piece */
 
 template <int NDW>
 struct K2BoundJob { // per-job state of the bound recurrence and of its suspect list (all wave-uniform but b*/Mprev)
@@ -593,99 +599,89 @@ struct K2BoundJob { // per-job state of the bound recurrence and of its suspect 
 #endif
     static constexpr int GS = K2B_GS > NDW ? NDW : K2B_GS; // 4-pixel groups per recurrence group
     static constexpr int NG = (NDW + GS - 1) / GS;
-    uint32_t b0[NG], b1[NG], b2[NG], Mprev[NG];
-    uint32_t npend, spent, hot, jidx;
+    // vertical 1-4-6-4-1 of the group masses as four cascaded two-tap sums (binomial = (1 + z^-1)^4): per group four
+    // plain 32-bit adds and no shift / multiply; P[k][parity] = output of stage k at the previous row of that parity
+    // (the row loops are unrolled by two, so nothing is ever copied)
+    uint32_t P[4][2][NG];
+    uint32_t npend, hot, jidx;
     int handover; // < 0: scanning; >= 0: first output row left to the row machine (or "nothing to do")
 };
 
+// one input row of one job: group masses m[] -> bound of output row y; suspects go to the job's LDS list.
+// Everything that steers control flow is read through SGPRs (ballots, s_bcnt1), so the scan loops compile to scalar
+// branches.
 template <int NDW>
-__device__ __forceinline__ void k2b_flush(K2BoundJob<NDW> &J, uint32_t *pend, uint2 *__restrict__ list,
-                                          uint32_t *__restrict__ nlist, int lane)
-{
-    if (J.npend == 0)
-        return;
-    __syncthreads(); // (one wave: orders the LDS writes before the reads below)
-    uint32_t base = 0;
-    if (lane == 0)
-        base = atomicAdd(nlist, J.npend);
-    base = __shfl(base, 0);
-#pragma unroll 1 // rare path: unrolled, its LDS reads would set the kernel's register allocation
-    for (uint32_t i = lane; i < J.npend; i += 64)
-        list[base + i] = make_uint2(J.jidx, pend[i]);
-    __syncthreads();
-    J.spent += J.npend;
-    J.npend = 0;
-}
-
-// one input row of one job: group masses m[] -> bound of output row y; suspects go to the job's list
-template <int NDW>
-__device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const uint32_t (&m)[NDW], bool emit, int y, bool active,
-                                        bool first_lane, bool last_lane, int lane, uint32_t ngroups, uint32_t budget,
-                                        uint32_t *pend, uint2 *__restrict__ list, uint32_t *__restrict__ nlist)
+__device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const int par, const uint32_t (&m)[NDW], bool emit, int y,
+                                        bool active, bool first_lane, bool last_lane, int lane, uint32_t ngroups,
+                                        uint32_t budget, uint32_t *pend)
 {
     uint32_t mL = __builtin_amdgcn_update_dpp(0u, m[NDW - 1], DPP_WAVE_SHR1, 0xf, 0xf, false);
     uint32_t mR = __builtin_amdgcn_update_dpp(0u, m[0], DPP_WAVE_SHL1, 0xf, 0xf, false);
     mL = first_lane ? m[0] : mL;
     mR = last_lane ? m[NDW - 1] : mR;
     constexpr int NG = K2BoundJob<NDW>::NG;
+    constexpr int GS = K2BoundJob<NDW>::GS;
     uint32_t B[NG];
-    uint32_t worst = 0;
+    uint32_t worst = 0; // OR of the bounds: each half >= that half of every group's bound (cheaper than a packed max)
 #pragma unroll
     for (int g = 0; g < NG; g++) {
-        constexpr int GS = K2BoundJob<NDW>::GS;
         const int g0 = GS * g, g1 = GS * g + GS - 1 < NDW ? GS * g + GS - 1 : NDW - 1; // first and last 4-pixel group
         uint32_t own = m[g0];
 #pragma unroll
         for (int q = g0 + 1; q <= g1; q++)
             own += m[q];
         const uint32_t M = (g0 ? m[g0 - 1] : mL) + own + (g1 + 1 < NDW ? m[g1 + 1] : mR);
-        B[g] = J.b0[g] + M;
-        const uint32_t M4 = M << 2;
-        J.b0[g] = J.b1[g] + M4;
-        J.b1[g] = pk_madk<6>(M, J.b2[g]);
-        J.b2[g] = J.Mprev[g] + M4;
-        J.Mprev[g] = M;
-        u16x2 w = __builtin_bit_cast(u16x2, worst), bb = __builtin_bit_cast(u16x2, B[g]);
-        worst = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(w, bb));
+        const uint32_t s1 = M + J.P[0][par ^ 1][g];
+        const uint32_t s2 = s1 + J.P[1][par ^ 1][g];
+        const uint32_t s3 = s2 + J.P[2][par ^ 1][g];
+        B[g] = s3 + J.P[3][par ^ 1][g];
+        J.P[0][par][g] = M;
+        J.P[1][par][g] = s1;
+        J.P[2][par][g] = s2;
+        J.P[3][par][g] = s3;
+        worst |= B[g];
     }
     const bool unsure = active && ((worst & 0xffffu) + (worst >> 16)) > 21u; // 6 * (lo + hi) < 128 <=> lo + hi <= 21
     if (!(emit && __builtin_amdgcn_ballot_w64(unsure)))
         return;
-    uint32_t fmask = 0; // one bit per 4-pixel group
-    if (active) {
+    // ---- rare: some group of this row cannot be proven zero -----------------------------------------------
+    unsigned long long bm[NG]; // lanes whose recurrence group g (GS 4-pixel groups) is suspect
+    bool mine[NG];
+    uint32_t total = 0;
 #pragma unroll
-        for (int g = 0; g < NG; g++)
-            if ((B[g] & 0xffffu) + (B[g] >> 16) > 21u)
-                fmask |= (((1u << K2BoundJob<NDW>::GS) - 1u) << (K2BoundJob<NDW>::GS * g)) & ((1u << NDW) - 1u);
+    for (int g = 0; g < NG; g++) {
+        mine[g] = active && ((B[g] & 0xffffu) + (B[g] >> 16)) > 21u;
+        bm[g] = __builtin_amdgcn_ballot_w64(mine[g]);
+        const int nq = GS * g + GS <= NDW ? GS : NDW - GS * g; // 4-pixel groups of this recurrence group
+        total += (uint32_t)nq * (uint32_t)__builtin_popcountll(bm[g]);
     }
-    const uint32_t c = __builtin_popcount(fmask);
-    uint32_t inc = c;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t v = __shfl_up(inc, o);
-        if (lane >= o)
-            inc += v;
-    }
-    const uint32_t total = __shfl(inc, 63);
     J.hot += total > 32u; // one row of the row machine costs about as much as 30 exact groups
-    if (J.hot >= 4u || J.spent + J.npend + total > budget) {
+    if (J.hot >= 4u || J.npend + total > budget) {
         J.handover = y;
         return;
     }
-    if (J.npend + total > K2B_PEND)
-        k2b_flush<NDW>(J, pend, list, nlist, lane);
-    uint32_t pos = J.npend + inc - c;
     const uint32_t code0 = (uint32_t)y * ngroups + (uint32_t)lane * NDW;
+    uint32_t base = J.npend;
 #pragma unroll
-    for (int g = 0; g < NDW; g++)
-        if (fmask & (1u << g))
-            pend[pos++] = code0 + g;
-    J.npend += total;
+    for (int g = 0; g < NG; g++) {
+        const unsigned long long b = bm[g];
+        if (b) {
+            const int nq = GS * g + GS <= NDW ? GS : NDW - GS * g;
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+            if (mine[g]) {
+#pragma unroll
+                for (int q = 0; q < nq; q++)
+                    pend[base + (uint32_t)nq * below + q] = code0 + GS * g + q;
+            }
+            base += (uint32_t)nq * (uint32_t)__builtin_popcountll(b);
+        }
+    }
+    J.npend = base;
 }
 
 // Store mode of the bound-and-verify pass: a row the scan is responsible for (everything above the hand-over row) is
 // written as zeros by the scan itself -- proven rows ARE zero, and the few suspect groups of a row are overwritten by
-// k2_exact_groups, which runs after the scan on the same stream.
+// the wave's own tail.
 template <int NDW>
 __device__ __forceinline__ void k2b_store_zero_row(uint8_t *__restrict__ row)
 {
@@ -695,14 +691,123 @@ __device__ __forceinline__ void k2b_store_zero_row(uint8_t *__restrict__ row)
         po[d] = 0;
 }
 
-template <int NDW, bool STORE>
+// The wave's tail: D for the four pixels of every remembered group, straight from the definition
+// (AnalyzerUnit.cpp:351-370), one lane per group; histogram by global atomics (rare), optional store / candidates.
+template <bool COMPACT, bool STORE>
+__device__ __forceinline__ void k2b_tail(const uint32_t *pend, uint32_t npend, const abub_job jb, const uint8_t *__restrict__ frames,
+                                         const uint8_t *__restrict__ sigma6, int W, int H, uint32_t *__restrict__ hist,
+                                         uint8_t *__restrict__ diff, const Compact &cp, int lane)
+{
+    if (npend == 0)
+        return;
+    __syncthreads(); // (one wave: orders the LDS writes of the scan before the reads below)
+    const size_t P = (size_t)W * H;
+    const uint32_t ngroups = (uint32_t)W / 4;
+    const uint8_t *cur = frames + (size_t)jb.cur * P;
+    const uint8_t *ref = frames + (size_t)jb.ref * P;
+    const uint8_t *sg = sigma6 + (size_t)jb.model * P;
+    // with the fused candidate list the whole wave iterates together (the reservation shuffles)
+    const uint32_t nloop = COMPACT ? (npend + 63u) & ~63u : npend;
+#pragma unroll 1
+    for (uint32_t e = lane; e < nloop; e += 64) {
+        uint32_t Dv[4] = {0, 0, 0, 0};
+        uint32_t pix0 = 0;
+        if (e < npend) {
+            const uint32_t code = pend[e];
+            const int y = (int)(code / ngroups), x0 = (int)(code % ngroups) * 4;
+            // interior groups read their 12-byte window as three aligned dwords per array and row; the two edge groups
+            // (reflected columns) take the byte path
+            const bool interior = x0 >= 4 && x0 + 8 <= W;
+            int xs[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                xs[j] = reflect101(x0 - 2 + j, W);
+            int Sp[4] = {0, 0, 0, 0}, Sn[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const size_t ro = (size_t)reflect101(y - 2 + i, H) * W;
+                int pp[8], nn[8];
+                if (interior) {
+                    const uint32_t *pc = reinterpret_cast<const uint32_t *>(cur + ro + x0 - 4);
+                    const uint32_t *pr = reinterpret_cast<const uint32_t *>(ref + ro + x0 - 4);
+                    const uint32_t *ps = reinterpret_cast<const uint32_t *>(sg + ro + x0 - 4);
+                    const uint32_t cw[3] = {pc[0], pc[1], pc[2]}, rw[3] = {pr[0], pr[1], pr[2]}, sw[3] = {ps[0], ps[1], ps[2]};
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int q = (2 + j) >> 2, sh = 8 * ((2 + j) & 3);
+                        const int c = (cw[q] >> sh) & 0xff, r = (rw[q] >> sh) & 0xff, s6 = (sw[q] >> sh) & 0xff;
+                        int a = c - r - s6, b = r - c - s6;
+                        pp[j] = a > 0 ? a : 0;
+                        nn[j] = b > 0 ? b : 0;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int c = cur[ro + xs[j]], r = ref[ro + xs[j]], s6 = sg[ro + xs[j]];
+                        int a = c - r - s6, b = r - c - s6;
+                        pp[j] = a > 0 ? a : 0;
+                        nn[j] = b > 0 ? b : 0;
+                    }
+                }
+                const int wv = (i == 0 || i == 4) ? 1 : (i == 2 ? 6 : 4);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    Sp[k] += wv * (pp[k] + 4 * pp[k + 1] + 6 * pp[k + 2] + 4 * pp[k + 3] + pp[k + 4]);
+                    Sn[k] += wv * (nn[k] + 4 * nn[k + 1] + 6 * nn[k + 2] + 4 * nn[k + 3] + nn[k + 4]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int a = (Sp[k] + 128) >> 8, b = (Sn[k] + 128) >> 8;
+                const int d = a > b ? a - b : b - a;
+                Dv[k] = (uint32_t)d;
+                if (d)
+                    atomicAdd(&hist[(size_t)jb.out * 256 + d], 1u);
+            }
+            if (STORE) // (the scan wrote this row as zeros; x0 is a multiple of 4 and W % 4 == 0: an aligned dword)
+                *reinterpret_cast<uint32_t *>(diff + (size_t)jb.out * P + (size_t)y * W + x0) =
+                    Dv[0] | (Dv[1] << 8) | (Dv[2] << 16) | (Dv[3] << 24);
+            pix0 = (uint32_t)(y * W + x0);
+        }
+        if (COMPACT) { // candidates (value > cut) of the wave's groups: one reservation per wave
+            uint32_t c = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                c += (int)Dv[k] > cp.thr;
+            uint32_t pos = compact_reserve(cp, c);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                compact_put(cp, pos, Dv[k], pix0 + k);
+        }
+    }
+}
+
+// hand the rows [y, y1) of `unit` to the row machine, in pieces of K2B_SUB rows (capacity: see launch_k2_rows)
+__device__ __forceinline__ void k2b_hand_over(uint2 *__restrict__ units, uint32_t *__restrict__ nunits, uint32_t unit, int y, int y1,
+                                              int lane)
+{
+    const int np = (y1 - y + K2B_SUB - 1) / K2B_SUB;
+    if (np <= 0)
+        return;
+    uint32_t base = 0;
+    if (lane == 0)
+        base = atomicAdd(nunits, (uint32_t)np);
+    base = __builtin_amdgcn_readfirstlane(base);
+    for (int i = lane; i < np; i += 64) {
+        const int a = y + i * K2B_SUB, b = a + K2B_SUB < y1 ? a + K2B_SUB : y1;
+        units[base + i] = make_uint2(unit, (uint32_t)a | ((uint32_t)b << 16));
+    }
+}
+
+template <int NDW, bool STORE, bool COMPACT>
 __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ frames,
                                                     const uint8_t *__restrict__ sigma6,
                                                     const abub_job *__restrict__ jobs, int W, int H,
-                                                    int rows_per_chunk, int nchunks, uint2 *__restrict__ list,
-                                                    uint32_t *__restrict__ nlist, uint32_t budget,
+                                                    int rows_per_chunk, int nchunks, uint32_t budget,
                                                     uint2 *__restrict__ units, uint32_t *__restrict__ nunits,
-                                                    uint8_t *__restrict__ diff)
+                                                    uint32_t *__restrict__ hist, uint8_t *__restrict__ diff,
+                                                    const int32_t *__restrict__ cthr, uint32_t *pairs, uint32_t pcap,
+                                                    uint32_t *pcount, uint32_t slot_base)
 {
     constexpr int NP = 2 * NDW;
     __shared__ uint32_t pend[K2B_PEND];
@@ -730,8 +835,10 @@ __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ 
     K2BoundJob<NDW> J;
 #pragma unroll
     for (int g = 0; g < K2BoundJob<NDW>::NG; g++)
-        J.b0[g] = J.b1[g] = J.b2[g] = J.Mprev[g] = 0;
-    J.npend = J.spent = J.hot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            J.P[q][0][g] = J.P[q][1][g] = 0;
+    J.npend = J.hot = 0;
     J.jidx = (uint32_t)job;
     J.handover = -1;
     uint8_t *dbase = STORE ? diff + (size_t)jb.out * P + xoff : nullptr;
@@ -752,16 +859,21 @@ __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ 
 #pragma unroll
                 for (int g = 0; g < NDW; g++)
                     m[g] = (Xp[2 * g] + Xn[2 * g]) + (Xp[2 * g + 1] + Xn[2 * g + 1]);
-                k2b_row<NDW>(J, m, tt >= 4 && tt < T, y0 + tt - 4, active, first_lane, last_lane, lane, ngroups, budget,
-                             pend, list, nlist);
+                k2b_row<NDW>(J, u, m, tt >= 4 && tt < T, y0 + tt - 4, active, first_lane, last_lane, lane, ngroups, budget, pend);
                 if (STORE && tt >= 4 && tt < T && J.handover < 0 && active)
                     k2b_store_zero_row<NDW>(dbase + (ptrdiff_t)(y0 + tt - 4) * W);
             }
         }
     }
-    k2b_flush<NDW>(J, pend, list, nlist, lane);
-    if (J.handover >= 0 && lane == 0)
-        units[atomicAdd(nunits, 1u)] = make_uint2((uint32_t)unit, (uint32_t)J.handover); // capacity = number of units
+    if (J.handover >= 0)
+        k2b_hand_over(units, nunits, (uint32_t)unit, J.handover, y1, lane);
+    Compact cp;
+    cp.pairs = COMPACT ? pairs : nullptr;
+    cp.count = pcount;
+    cp.cap = pcap;
+    cp.slot = jb.out + slot_base;
+    cp.thr = COMPACT ? cthr[jb.out] : 255;
+    k2b_tail<COMPACT, STORE>(pend, J.npend, jb, frames, sigma6, W, H, hist, diff, cp, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -769,8 +881,6 @@ __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ 
 // in which job q takes the cur frame of job q - S as its ref (FindTriggerFrame: S = 2, or 1 for small training sets).
 // One wave serves up to K jobs of one such chain for one chunk: every frame row is loaded once and used as the cur
 // row of one job and the ref row of the next, sigma6 once for all -- (K + 2) / K row loads per job instead of 3.
-// The scan is bound by the number of row requests the memory system takes (tools/k2_readonly.cpp: 0.30 us per job
-// with 3 streams per job, 0.24 with K = 2, 0.22 with K = 4), not by bytes from HBM.
 // The chain property is only a hint: the wave checks it on the job records and hands units it cannot chain to the row
 // machine, so any job list gives the same histograms as k2_bound_scan / k2_rows.
 // ------------------------------------------------------------------------------------------------
@@ -778,10 +888,9 @@ template <int NDW, int K, bool STORE>
 __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__ frames,
                                                      const uint8_t *__restrict__ sigma6,
                                                      const abub_job *__restrict__ jobs, int L, int S, int nslot, int W,
-                                                     int H, int rows_per_chunk, int nchunks, uint2 *__restrict__ list,
-                                                     uint32_t *__restrict__ nlist, uint32_t budget,
+                                                     int H, int rows_per_chunk, int nchunks, uint32_t budget,
                                                      uint2 *__restrict__ units, uint32_t *__restrict__ nunits,
-                                                     uint8_t *__restrict__ diff)
+                                                     uint32_t *__restrict__ hist, uint8_t *__restrict__ diff)
 {
     __shared__ uint32_t pend[K][K2B_PEND];
     const int lane = threadIdx.x;
@@ -808,19 +917,19 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
         jb[t] = jobs[J[t].jidx];
     }
     const int y0 = chunk * rows_per_chunk;
+    int y1 = y0 + rows_per_chunk;
+    if (y1 > H)
+        y1 = H;
     bool chained = true;
 #pragma unroll
     for (int t = 1; t < K; t++)
         if (t < k && (jb[t].ref != jb[t - 1].cur || jb[t].model != jb[0].model))
             chained = false;
     if (!chained) { // not the structure promised: every unit goes to the row machine whole
-        if (lane < k) {
-            uint32_t j = J[0].jidx;
 #pragma unroll
-            for (int t = 1; t < K; t++)
-                j = lane == t ? J[t].jidx : j;
-            units[atomicAdd(nunits, 1u)] = make_uint2(j * (uint32_t)nchunks + (uint32_t)chunk, (uint32_t)y0);
-        }
+        for (int t = 0; t < K; t++)
+            if (t < k)
+                k2b_hand_over(units, nunits, J[t].jidx * (uint32_t)nchunks + (uint32_t)chunk, y0, y1, lane);
         return;
     }
     const size_t P = (size_t)W * H;
@@ -839,21 +948,24 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
 #pragma unroll
     for (int t = 0; t < K; t++)
         dbase[t] = STORE ? diff + (size_t)jb[t].out * P + xoff : nullptr;
-    int y1 = y0 + rows_per_chunk;
-    if (y1 > H)
-        y1 = H;
     const int T = y1 - y0 + 4;
     const uint32_t ngroups = (uint32_t)W / 4;
 #pragma unroll
     for (int t = 0; t < K; t++) {
 #pragma unroll
         for (int g = 0; g < K2BoundJob<NDW>::NG; g++)
-            J[t].b0[g] = J[t].b1[g] = J[t].b2[g] = J[t].Mprev[g] = 0;
-        J[t].npend = J[t].spent = J[t].hot = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                J[t].P[q][0][g] = J[t].P[q][1][g] = 0;
+        J[t].npend = J[t].hot = 0;
         J[t].handover = t < k ? -1 : 0x7fffffff; // (jobs beyond k do nothing and report nothing)
     }
 
-    uint32_t raw[2][K + 2][NDW]; // [K + 1] = sigma6
+    // rows are fetched one step ahead through two register sets ([K + 1] = sigma6); the loop is unrolled by two so
+    // that each set -- and each parity of the recurrence state -- is a fixed set of registers.  (Fetching two steps
+    // ahead was measured equal: the scan is bound by VALU issue at the clock the chip holds under HBM load.)
+    constexpr int PF = 1, U = 2;
+    uint32_t raw[U][K + 2][NDW];
 #define K2C_LOAD(SL, Y)                                                                       \
     {                                                                                         \
         const size_t o_ = (size_t)(Y) * W + xoff;                                             \
@@ -865,9 +977,13 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
         const uint32_t *ps_ = reinterpret_cast<const uint32_t *>(sg + o_);                    \
         _Pragma("unroll") for (int d = 0; d < NDW; d++) raw[SL][K + 1][d] = ps_[d];           \
     }
-    K2C_LOAD(0, reflect101(y0 - 2, H));
-    const int Tpad = (T + 1) & ~1;
-    for (int t0 = 0; t0 < Tpad; t0 += 2) {
+#pragma unroll
+    for (int q = 0; q < PF; q++) {
+        const int tq = q < T ? q : T - 1;
+        K2C_LOAD(q, reflect101(y0 - 2 + tq, H));
+    }
+    const int Tpad = (T + U - 1) / U * U;
+    for (int t0 = 0; t0 < Tpad; t0 += U) {
         bool all_done = true;
 #pragma unroll
         for (int t = 0; t < K; t++)
@@ -875,10 +991,10 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
         if (all_done)
             break;
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < U; u++) {
             const int tt = t0 + u;
-            const int tn = tt + 1 < T ? tt + 1 : T - 1;
-            K2C_LOAD(u ^ 1, reflect101(y0 - 2 + tn, H));
+            const int tn = tt + PF < T ? tt + PF : T - 1;
+            K2C_LOAD((u + PF) % U, reflect101(y0 - 2 + tn, H));
             // widened frame rows (pw / cw) and frame + sigma6 (ps / cs): each is computed once per frame and serves the
             // job that has the frame as cur and the job that has it as ref
             uint32_t sw[2 * NDW], pw[2 * NDW], ps[2 * NDW];
@@ -907,8 +1023,8 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
                     for (int g = 0; g < NDW; g++) // sat(c - (r + s)) + sat(r - (c + s)), both pairs of the group
                         m[g] = (pk_subsat(cw[2 * g], ps[2 * g]) + pk_subsat(pw[2 * g], cs[2 * g])) +
                                (pk_subsat(cw[2 * g + 1], ps[2 * g + 1]) + pk_subsat(pw[2 * g + 1], cs[2 * g + 1]));
-                    k2b_row<NDW>(J[t], m, tt >= 4 && tt < T, y0 + tt - 4, active, first_lane, last_lane, lane, ngroups,
-                                 budget, pend[t], list, nlist);
+                    k2b_row<NDW>(J[t], u, m, tt >= 4 && tt < T, y0 + tt - 4, active, first_lane, last_lane, lane, ngroups,
+                                 budget, pend[t]);
                     if (STORE && tt >= 4 && tt < T && J[t].handover < 0 && active)
                         k2b_store_zero_row<NDW>(dbase[t] + (ptrdiff_t)(y0 + tt - 4) * W);
                 }
@@ -921,133 +1037,18 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
         }
     }
 #undef K2C_LOAD
+    Compact cp;
+    cp.pairs = nullptr;
+    cp.count = nullptr;
+    cp.cap = 0;
+    cp.slot = 0;
+    cp.thr = 255;
 #pragma unroll
     for (int t = 0; t < K; t++) {
         if (t < k) {
-            k2b_flush<NDW>(J[t], pend[t], list, nlist, lane);
-            if (J[t].handover >= 0 && lane == 0)
-                units[atomicAdd(nunits, 1u)] =
-                    make_uint2(J[t].jidx * (uint32_t)nchunks + (uint32_t)chunk, (uint32_t)J[t].handover);
-        }
-    }
-}
-
-// one lane per listed group: D for its four pixels, straight from the definition (AnalyzerUnit.cpp:351-370)
-template <bool COMPACT, bool STORE>
-__global__ __launch_bounds__(256) void k2_exact_groups(const uint8_t *__restrict__ frames,
-                                                       const uint8_t *__restrict__ sigma6,
-                                                       const abub_job *__restrict__ jobs, int W, int H,
-                                                       const uint2 *__restrict__ list, const uint32_t *__restrict__ nlist,
-                                                       uint32_t listcap, uint32_t *__restrict__ hist,
-                                                       const int32_t *__restrict__ cthr, uint32_t *pairs, uint32_t pcap,
-                                                       uint32_t *pcount, uint32_t slot_base, uint8_t *__restrict__ diff)
-{
-    uint32_t n = *nlist;
-    if (n > listcap)
-        n = listcap;
-    const size_t P = (size_t)W * H;
-    const uint32_t ngroups = (uint32_t)W / 4;
-    // with the fused candidate list whole waves iterate together (the reservation below shuffles)
-    const uint32_t nloop = COMPACT ? (n + 63u) & ~63u : n;
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < nloop; e += gridDim.x * blockDim.x) {
-        uint32_t Dv[4] = {0, 0, 0, 0};
-        uint32_t cslot = 0, pix0 = 0;
-        int thr = 255;
-        if (e < n) {
-        const uint2 en = list[e];
-        const abub_job jb = jobs[en.x];
-        const int y = (int)(en.y / ngroups), x0 = (int)(en.y % ngroups) * 4;
-        const uint8_t *cur = frames + (size_t)jb.cur * P;
-        const uint8_t *ref = frames + (size_t)jb.ref * P;
-        const uint8_t *sg = sigma6 + (size_t)jb.model * P;
-        // interior groups read their 12-byte window as three aligned dwords per array and row; the two edge groups
-        // (reflected columns) take the byte path
-        const bool interior = x0 >= 4 && x0 + 8 <= W;
-        int xs[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            xs[j] = reflect101(x0 - 2 + j, W);
-        int Sp[4] = {0, 0, 0, 0}, Sn[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < 5; i++) {
-            const size_t ro = (size_t)reflect101(y - 2 + i, H) * W;
-            int pp[8], nn[8];
-            if (interior) {
-                const uint32_t *pc = reinterpret_cast<const uint32_t *>(cur + ro + x0 - 4);
-                const uint32_t *pr = reinterpret_cast<const uint32_t *>(ref + ro + x0 - 4);
-                const uint32_t *ps = reinterpret_cast<const uint32_t *>(sg + ro + x0 - 4);
-                const uint32_t cw[3] = {pc[0], pc[1], pc[2]}, rw[3] = {pr[0], pr[1], pr[2]}, sw[3] = {ps[0], ps[1], ps[2]};
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const int q = (2 + j) >> 2, sh = 8 * ((2 + j) & 3);
-                    const int c = (cw[q] >> sh) & 0xff, r = (rw[q] >> sh) & 0xff, s6 = (sw[q] >> sh) & 0xff;
-                    int a = c - r - s6, b = r - c - s6;
-                    pp[j] = a > 0 ? a : 0;
-                    nn[j] = b > 0 ? b : 0;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const int c = cur[ro + xs[j]], r = ref[ro + xs[j]], s6 = sg[ro + xs[j]];
-                    int a = c - r - s6, b = r - c - s6;
-                    pp[j] = a > 0 ? a : 0;
-                    nn[j] = b > 0 ? b : 0;
-                }
-            }
-            const int wv = (i == 0 || i == 4) ? 1 : (i == 2 ? 6 : 4);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                Sp[k] += wv * (pp[k] + 4 * pp[k + 1] + 6 * pp[k + 2] + 4 * pp[k + 3] + pp[k + 4]);
-                Sn[k] += wv * (nn[k] + 4 * nn[k + 1] + 6 * nn[k + 2] + 4 * nn[k + 3] + nn[k + 4]);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int a = (Sp[k] + 128) >> 8, b = (Sn[k] + 128) >> 8;
-            const int d = a > b ? a - b : b - a;
-            Dv[k] = (uint32_t)d;
-            if (d)
-                atomicAdd(&hist[(size_t)jb.out * 256 + d], 1u);
-        }
-        if (STORE) // (the scan wrote this row as zeros; x0 is a multiple of 4 and W % 4 == 0: an aligned dword)
-            *reinterpret_cast<uint32_t *>(diff + (size_t)jb.out * P + (size_t)y * W + x0) =
-                Dv[0] | (Dv[1] << 8) | (Dv[2] << 16) | (Dv[3] << 24);
-        if (COMPACT) {
-            cslot = jb.out + slot_base;
-            pix0 = (uint32_t)(y * W + x0);
-            thr = cthr[jb.out];
-        }
-        } // e < n
-        if (COMPACT) { // candidates (value > cut) of the wave's groups: one reservation per wave
-            Compact cp;
-            cp.pairs = pairs;
-            cp.count = pcount;
-            cp.cap = pcap;
-            cp.slot = cslot;
-            cp.thr = thr;
-            uint32_t c = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                c += (int)Dv[k] > thr;
-            const int wl = threadIdx.x & 63;
-            uint32_t inc = c;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                uint32_t v = __shfl_up(inc, o);
-                if (wl >= o)
-                    inc += v;
-            }
-            const uint32_t total = __shfl(inc, 63);
-            uint32_t base = 0;
-            if (total) {
-                if (wl == 0)
-                    base = atomicAdd(pcount, total);
-                base = __shfl(base, 0);
-            }
-            uint32_t pos = base + inc - c;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                compact_put(cp, pos, Dv[k], pix0 + k);
+            if (J[t].handover >= 0)
+                k2b_hand_over(units, nunits, J[t].jidx * (uint32_t)nchunks + (uint32_t)chunk, J[t].handover, y1, lane);
+            k2b_tail<false, STORE>(pend[t], J[t].npend, jb[t], frames, sigma6, W, H, hist, diff, cp, lane);
         }
     }
 }
@@ -1222,7 +1223,7 @@ static void launch_k2_rows_pf(const uint8_t *frames, const uint8_t *sigma6, cons
 struct K2Options {
     int bound = 1;     // 0: always the full row machine (k2_rows); 1: bound-and-verify (trigger-only AND store mode)
     int chain = 2;     // jobs per wave in the chained scan (2 or 3; 0 = never chain)
-    int budget = 1024; // suspects a chunk may list before it hands its rows over
+    int budget = 512;  // suspects a chunk may remember (LDS) before it hands its rows over (<= K2B_PEND)
     int pf = 1;        // software-prefetch depth of the row machine in rows (1 or 2)
     bool loaded = false;
 };
@@ -1271,27 +1272,22 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
                            const CompactArgs &ca, hipStream_t st)
 {
     const K2Options opt = k2_options();
-    if (opt.bound && (size_t)H * (size_t)(W / 4) < ((size_t)1 << 32)) { // (row, group) codes are 32-bit
-        // bound-and-verify (see k2_bound_scan); with `diff` the scan also writes the rows it proves (or lists)
+    if (opt.bound && (size_t)H * (size_t)(W / 4) < ((size_t)1 << 32) && H < 65536) { // (row, group) codes are 32-bit
+        // bound-and-verify (see k2_bound_scan); with `diff` the scan also writes the rows it proves (or remembers)
         const size_t nunits = (size_t)njobs * nchunks;
-        // every chunk may list up to `budget` suspicious groups (then it hands its remaining rows to the row machine),
-        // so the list can never overflow; 64 M entries = 512 MB at most
-        size_t budget = (size_t)opt.budget;
-        if (nunits * budget > ((size_t)64 << 20))
-            budget = ((size_t)64 << 20) / nunits;
-        const size_t cap = nunits * budget;
-        const size_t unitBytes = (nunits * sizeof(uint2) + 255) & ~(size_t)255;
-        const size_t bytes = 256 + unitBytes + cap * sizeof(uint2) + 256;
+        // a chunk remembers up to `budget` suspicious groups in LDS, then it hands its remaining rows to the row machine
+        const uint32_t budget = (uint32_t)(opt.budget < K2B_PEND ? opt.budget : K2B_PEND);
+        const size_t unitCap = nunits * (size_t)((R + K2B_SUB - 1) / K2B_SUB); // handed-over pieces, worst case
+        const size_t bytes = 256 + unitCap * sizeof(uint2) + 256;
         std::unique_lock<std::mutex> hold;
         uint8_t *scr = (uint8_t *)k2_scratch(st, bytes, hold);
         if (!scr)
             return set_err(ABUB_E_HIP, "abub_diff_hist_dev: scratch allocation failed");
-        uint32_t *counters = (uint32_t *)scr; // [0] = list entries, [1] = handed-over units
+        uint32_t *counters = (uint32_t *)scr; // [0] = handed-over pieces
         uint2 *units = (uint2 *)(scr + 256);
-        uint2 *list = (uint2 *)(scr + 256 + unitBytes);
-        HIPCHK(hipMemsetAsync(counters, 0, 2 * sizeof(uint32_t), st));
+        HIPCHK(hipMemsetAsync(counters, 0, sizeof(uint32_t), st));
         const int L = ca.chain_len, S = ca.chain_stride;
-        if (opt.chain >= 2 && L > 0 && S > 0 && S <= 8 && njobs % L == 0) {
+        if (opt.chain >= 2 && L > 0 && S > 0 && S <= 8 && njobs % L == 0 && !ca.cthr) {
             const int Kc = opt.chain >= 3 ? 3 : 2;
             int nslot = 0;
             for (int r = 0; r < S; r++) {
@@ -1301,49 +1297,57 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
             const dim3 grid((unsigned)((size_t)(njobs / L) * nslot * nchunks));
 #define K2C_LAUNCH(KK, ST)                                                                                          \
     hipLaunchKernelGGL((k2_bound_chain<NDW, KK, ST>), grid, dim3(64), 0, st, frames, sigma6, jobs, L, S, nslot, W,  \
-                       H, R, nchunks, list, counters, (uint32_t)budget, units, counters + 1, diff)
+                       H, R, nchunks, budget, units, counters, hist, diff)
             if (Kc == 3) {
-                if (diff)
+                if (diff) {
                     K2C_LAUNCH(3, true);
-                else
+                } else {
                     K2C_LAUNCH(3, false);
+                }
             } else {
-                if (diff)
+                if (diff) {
                     K2C_LAUNCH(2, true);
-                else
+                } else {
                     K2C_LAUNCH(2, false);
+                }
             }
 #undef K2C_LAUNCH
         } else {
-            if (diff)
-                hipLaunchKernelGGL((k2_bound_scan<NDW, true>), dim3((unsigned)nunits), dim3(64), 0, st, frames, sigma6, jobs,
-                                   W, H, R, nchunks, list, counters, (uint32_t)budget, units, counters + 1, diff);
-            else
-                hipLaunchKernelGGL((k2_bound_scan<NDW, false>), dim3((unsigned)nunits), dim3(64), 0, st, frames, sigma6, jobs,
-                                   W, H, R, nchunks, list, counters, (uint32_t)budget, units, counters + 1, diff);
+#define K2S_LAUNCH(ST, CO)                                                                                          \
+    hipLaunchKernelGGL((k2_bound_scan<NDW, ST, CO>), dim3((unsigned)nunits), dim3(64), 0, st, frames, sigma6, jobs, \
+                       W, H, R, nchunks, budget, units, counters, hist, diff, ca.cthr, ca.pairs, ca.cap, ca.count,  \
+                       ca.slot_base)
+            if (ca.cthr) {
+                if (diff)
+                    K2S_LAUNCH(true, true);
+                else
+                    K2S_LAUNCH(false, true);
+            } else {
+                if (diff)
+                    K2S_LAUNCH(true, false);
+                else
+                    K2S_LAUNCH(false, false);
+            }
+#undef K2S_LAUNCH
         }
-        const unsigned g3 = (unsigned)(nunits < 2048 ? nunits : 2048);
-        // the listed groups exactly, then the handed-over rows through the row machine's list mode; with the fused
-        // candidate list (cthr) both emit the candidates, with `diff` both write their pixels
-#define K2X_LAUNCH(CO, ST)                                                                                           \
-    hipLaunchKernelGGL((k2_exact_groups<CO, ST>), dim3(1024), dim3(256), 0, st, frames, sigma6, jobs, W, H, list,    \
-                       counters, (uint32_t)cap, hist, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base, diff);      \
-    hipLaunchKernelGGL((k2_rows<NDW, ST, 1, CO>), dim3(g3), dim3(64), 0, st, frames, sigma6, jobs, W, H, R, nchunks,  \
-                       hist, diff, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base, units, counters + 1)
+        // the handed-over row ranges through the row machine's list mode (grid-stride over the pieces); with the fused
+        // candidate list (cthr) it emits the candidates, with `diff` it writes its rows
+        const unsigned g3 = (unsigned)(unitCap < 4096 ? unitCap : 4096);
+#define K2R_LAUNCH(ST, CO)                                                                                          \
+    hipLaunchKernelGGL((k2_rows<NDW, ST, 1, CO>), dim3(g3), dim3(64), 0, st, frames, sigma6, jobs, W, H, R, nchunks, \
+                       hist, diff, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base, units, counters)
         if (ca.cthr) {
-            if (diff) {
-                K2X_LAUNCH(true, true);
-            } else {
-                K2X_LAUNCH(true, false);
-            }
+            if (diff)
+                K2R_LAUNCH(true, true);
+            else
+                K2R_LAUNCH(false, true);
         } else {
-            if (diff) {
-                K2X_LAUNCH(false, true);
-            } else {
-                K2X_LAUNCH(false, false);
-            }
+            if (diff)
+                K2R_LAUNCH(true, false);
+            else
+                K2R_LAUNCH(false, false);
         }
-#undef K2X_LAUNCH
+#undef K2R_LAUNCH
         return ABUB_OK;
     }
     // prefetch depth 1 won on MI355X: depth 2/3 rings cost a wave of occupancy and ran 10-17 % slower

@@ -28,6 +28,16 @@ void MemParser::AddFrames(const std::string &EventID, int camera, const std::vec
     std::sort(v.begin(), v.end(), [](const Frame &a, const Frame &b) { return a.name < b.name; });
 }
 
+void MemParser::AddNamedFrames(const std::string &EventID, int camera, const std::vector<std::string> &names,
+                               const std::vector<cv::Mat> *images)
+{
+    std::vector<Frame> &v = (*events_)[EventID][camera];
+    v.clear();
+    for (size_t k = 0; k < names.size(); ++k)
+        v.push_back(Frame{names[k], images && k < images->size() ? (*images)[k] : cv::Mat()});
+    std::sort(v.begin(), v.end(), [](const Frame &a, const Frame &b) { return a.name < b.name; });
+}
+
 int MemParser::GetImage(std::string EventID, std::string FrameName, cv::Mat &out)
 {
     auto ev = events_->find(EventID);

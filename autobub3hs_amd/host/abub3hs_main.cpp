@@ -21,6 +21,7 @@
 #include "ParseFolder/RawParser.hpp"
 #include "ParseFolder/ZipParser.hpp"
 #include "driver.hpp"
+#include "runbatch.hpp"
 
 static std::string usage()
 {
@@ -37,7 +38,12 @@ static std::string usage()
            "  -m, --mask_check\t\tuse camera masks in default directory. Not needed if directory specified\n"
            "  -D, --data_series = Str\tname of the data series, e.g. 40l-19, 30l-16, etc.\n"
            "  -e, --event = Int\t\tspecify a single event to process. Mostly just useful for debugging and testing\n"
-           "  --debug = Int\t\t\t3 digit int; eg: 101: first digit = localizer debug; second digit = multithread off; third digit = analyzer debug\n";
+           "  --debug = Int\t\t\t3 digit int; eg: 101: first digit = localizer debug; second digit = multithread off; third digit = analyzer debug\n"
+           "MI355X options:\n"
+           "  --gpus = Int\t\t\tGPUs to spread the event batches over (one worker thread per GPU; default 1)\n"
+           "  --gpu-shard = r/N\t\tprocess only the events whose index in the sorted event list is r modulo N\n"
+           "  --per-event\t\t\tone analyzer at a time like the reference's loop (also chosen by -e and --debug);\n"
+           "\t\t\t\tdefault: whole batches of events decoded into pinned memory and analysed together\n";
 }
 
 static bool eventNameOrderSort(const std::string &a, const std::string &b) { return std::stoi(a) < std::stoi(b); }
@@ -45,8 +51,8 @@ static bool eventNameOrderSort(const std::string &a, const std::string &b) { ret
 int main(int argc, char **argv)
 {
     std::string dataLoc, run_number, out_dir, mask_dir, data_series;
-    int event_user = -1, debug_mode = 0;
-    bool zipped = false, mask_check = false, help = argc == 1;
+    int event_user = -1, debug_mode = 0, ngpus = 1, shardRank = 0, shardWorld = 1;
+    bool zipped = false, mask_check = false, help = argc == 1, perEvent = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i], v;
         auto value = [&](std::string &dst) {
@@ -79,6 +85,17 @@ int main(int argc, char **argv)
         } else if (a.rfind("--debug", 0) == 0) {
             value(v);
             debug_mode = atoi(v.c_str());
+        } else if (a.rfind("--gpus", 0) == 0) {
+            value(v);
+            ngpus = std::max(1, atoi(v.c_str()));
+        } else if (a.rfind("--gpu-shard", 0) == 0) {
+            value(v);
+            if (sscanf(v.c_str(), "%d/%d", &shardRank, &shardWorld) != 2 || shardWorld < 1 || shardRank < 0 || shardRank >= shardWorld) {
+                std::cerr << "--gpu-shard expects r/N with 0 <= r < N" << std::endl;
+                return -1;
+            }
+        } else if (a == "--per-event") {
+            perEvent = true;
         } else {
             std::cerr << "unrecognised option '" << a << "'" << std::endl;
             return -1;
@@ -189,6 +206,49 @@ int main(int argc, char **argv)
     printf("***Training complete. AutoBub is now in detect mode***\n");
     delete header;
 
+    // ---- batched detect (default): every event of a batch decoded once into pinned memory, one set of launches per
+    // batch, output in event order.  The per-event loop below stays for -e / --debug / --per-event and as the
+    // fallback when the batched path declines the run.
+    if (const char *e = getenv("ABUB_PER_EVENT"))
+        perEvent = perEvent || atoi(e) != 0;
+    if (!perEvent && event_user < 0 && debug_mode == 0) {
+        abub::BatchedRunOptions bo;
+        bo.ngpus = ngpus;
+        if (const char *d = getenv("ABUB_DEVICE"))
+            bo.firstDevice = atoi(d);
+        bo.hostThreads = nthreads;
+        bo.decodeThreads = nthreads;
+        if (const char *t = getenv("ABUB_DECODE_THREADS"))
+            bo.decodeThreads = std::max(1, atoi(t));
+        if (const char *b = getenv("ABUB_BATCH_MB"))
+            bo.batchBytes = (size_t)std::max(1, atoi(b)) << 20;
+        bo.shardRank = shardRank;
+        bo.shardWorld = shardWorld;
+        bo.maskDir = mask_dir;
+        abub::BatchedRunStats bs;
+        std::string why;
+        int rc = 1;
+        try {
+            rc = abub::RunBatched(FileParser, EventList, Trainers, numCams, out_dir, run_number, frameOffset, bo, &bs, &why);
+        } catch (std::exception &e) {
+            std::cout << "batched detect failed: " << e.what() << std::endl;
+            return -6;
+        }
+        if (rc == 0) {
+            printf("batched detect: %d events in %d batches of <= %d on %d GPU(s), %lld frames %dx%d decoded (%lld undecodable), "
+                   "%.2f s total (list %.2f, decode %.2f, upload+GPU+host stages %.2f, write %.2f) = %.1f frames/s ingest-inclusive\n",
+                   bs.events, bs.batches, bs.eventsPerBatch, bs.gpus, bs.frames, bs.W, bs.H, bs.framesFailed, bs.total_s, bs.list_s,
+                   bs.decode_s, bs.gpu_s, bs.write_s, bs.total_s > 0 ? (bs.frames + bs.framesFailed) / bs.total_s : 0.0);
+            printf("run complete.\n");
+            for (Trainer *t : Trainers)
+                delete t;
+            delete FileParser;
+            printf("AutoBub done analyzing this run. Thank you.\n");
+            return 0;
+        }
+        std::cout << "batched detect not used (" << why << "): falling back to the per-event loop" << std::endl;
+    }
+
     // events in parallel, output appended in event order (the `ordered` clause :380-383)
     std::cout << "Total threads: " << nthreads << std::endl;
     std::atomic<int> next{0};
@@ -200,7 +260,8 @@ int main(int argc, char **argv)
             const int evi = next.fetch_add(1);
             if (evi >= (int)EventList.size())
                 break;
-            const bool skip = event_user >= 0 && evi != event_user; // compares the loop index, like upstream (:350)
+            const bool skip = (event_user >= 0 && evi != event_user) // compares the loop index, like upstream (:350)
+                              || (shardWorld > 1 && evi % shardWorld != shardRank);
             OutputWriter *out = nullptr;
             std::vector<AnalyzerUnit *> Analyzers;
             if (!skip) {

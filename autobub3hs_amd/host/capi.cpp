@@ -21,6 +21,7 @@
 #include "devctx.hpp"
 #include "driver.hpp"
 #include "hostlogic.hpp"
+#include "runbatch.hpp"
 
 namespace {
 
@@ -284,6 +285,52 @@ int abh_analyze(void *r, const char *ev, int cam, const char *maskdir)
     }
     delete A;
     return run->staged;
+}
+
+// A whole run (every event of the Run's parser, cameras 0..ncams-1, the Run's trained models) through the batched
+// pipeline into <outdir>abub3hs_<run>.txt; stats: [total_s, list_s, decode_s, gpu_s, write_s, frames, failed,
+// batches, events_per_batch, gpus].  Returns 0, 1 when the batched path declines the run, -1 on errors.
+int abh_run_batched(void *r, int ncams, const char *maskdir, const char *outdir, const char *run_number, int frameOffset,
+                    int ngpus, int nthreads, int decodeThreads, int batchMB, int shardRank, int shardWorld, double *statsOut)
+{
+    Run *run = (Run *)r;
+    try {
+        std::vector<std::string> events;
+        run->parser->GetEventDirLists(events);
+        std::sort(events.begin(), events.end(), [](const std::string &a, const std::string &b) { return std::stoi(a) < std::stoi(b); });
+        std::vector<Trainer *> trainers;
+        for (int c = 0; c < ncams; ++c) {
+            auto it = run->trainers.find(c);
+            if (it == run->trainers.end() || !it->second) {
+                run->error = "no trainer for camera";
+                return -1;
+            }
+            trainers.push_back(it->second);
+        }
+        abub::BatchedRunOptions bo;
+        bo.ngpus = std::max(1, ngpus);
+        bo.hostThreads = std::max(1, nthreads);
+        bo.decodeThreads = std::max(1, decodeThreads);
+        if (batchMB > 0)
+            bo.batchBytes = (size_t)batchMB << 20;
+        bo.shardRank = shardRank;
+        bo.shardWorld = std::max(1, shardWorld);
+        bo.maskDir = maskdir ? maskdir : "";
+        abub::BatchedRunStats bs;
+        std::string why;
+        const int rc = abub::RunBatched(run->parser, events, trainers, ncams, outdir, run_number, frameOffset, bo, &bs, &why);
+        if (rc != 0)
+            run->error = why;
+        if (statsOut) {
+            const double v[10] = {bs.total_s, bs.list_s, bs.decode_s, bs.gpu_s, bs.write_s, (double)bs.frames, (double)bs.framesFailed,
+                                  (double)bs.batches, (double)bs.eventsPerBatch, (double)bs.gpus};
+            std::memcpy(statsOut, v, sizeof v);
+        }
+        return rc;
+    } catch (std::exception &e) {
+        run->error = e.what();
+        return -1;
+    }
 }
 
 // reference main(): header once per run (AutoBubStart3.cpp:250-251)

@@ -33,8 +33,10 @@
 #include "BubbleLocalizer/L3Localizer.hpp"
 #include "ParseFolder/Parser.hpp"
 #include "common/CommonParameters.h"
+#include "PICOFormatWriter/PICOFormatWriterV4.hpp"
 #include "devctx.hpp"
 #include "hostlogic.hpp"
+#include "runbatch.hpp"
 
 namespace abub {
 extern bool g_quietAnalyzers;
@@ -67,8 +69,9 @@ public:
     const uint32_t *roundHists = nullptr; // [nslots][256] of the current round
     std::vector<PlannedImage> planned;
     int cur = -1;
+    const uint8_t *ok = nullptr; // per-frame "decoded" flags of a stack that came from disk (NULL: all good)
 
-    bool frameOk(int i) const override { return i >= 0 && i < F; }
+    bool frameOk(int i) const override { return i >= 0 && i < F && (!ok || ok[i]); }
     cv::Mat hostFrame(int) const override { return cv::Mat(); }
     const uint32_t *diffHist(int i, int off) override
     {
@@ -128,6 +131,18 @@ struct StackState {
     std::vector<BubbleOut> bubbles;
     int trig = 0, status = 0, loc_thres = 3, ok = 1;
 };
+
+} // namespace
+
+// What a batched driver knows about one (event, camera) stack that came from a Parser: the reference's event id,
+// the real frame names in the Parser's order and which of them decoded (host/runbatch: RunBatched)
+struct StackMeta {
+    std::string eventID;
+    std::vector<std::string> names;
+    std::vector<uint8_t> ok;
+};
+
+namespace {
 
 // Persistent worker pool shared by all stack groups: a group that is waiting for the GPU lends its
 // threads to the groups that are in their host stages (no per-call thread creation either).
@@ -279,6 +294,21 @@ public:
     std::vector<StackState> stacks;
     std::vector<Trainer *> trainers;
     MemParser parser;
+    // optional (runs ingested from a Parser): real ids / names / decode flags per stack; a stack may be shorter than F
+    std::vector<StackMeta> meta;
+    MemParser metaParser;
+    void setStackMeta(std::vector<StackMeta> &&m)
+    {
+        if ((int)m.size() != S)
+            throw std::runtime_error("RunPipeline::setStackMeta: one entry per stack expected");
+        meta = std::move(m);
+        metaParser = MemParser();
+        for (int s = 0; s < S; ++s) {
+            if ((int)meta[s].names.size() > F || meta[s].ok.size() != meta[s].names.size())
+                throw std::runtime_error("RunPipeline::setStackMeta: stack longer than the pipeline's frame count");
+            metaParser.AddNamedFrames(meta[s].eventID, s % C, meta[s].names);
+        }
+    }
     double tms[8] = {0};
     int rounds = 0;
     uint32_t lastPairs = 0;
@@ -516,13 +546,20 @@ private:
         }
         const int e = s / C, c = s % C;
         try {
-            std::vector<cv::Mat> frames((size_t)F);
-            for (int i = 0; i < F; ++i) {
+            const int Fs = meta.empty() ? F : (int)meta[s].names.size();
+            std::vector<cv::Mat> frames((size_t)Fs);
+            for (int i = 0; i < Fs; ++i) {
+                if (!meta.empty() && !meta[s].ok[i])
+                    continue; // undecodable on disk: stays an empty Mat (GetImage == -1)
                 frames[i].create(H, W, CV_8U);
                 HIPOK(hipMemcpy(frames[i].data, d_frames + ((size_t)s * F + i) * P, P, hipMemcpyDeviceToHost));
             }
             MemParser mp;
-            mp.AddFrames(std::to_string(e), c, frames, 10000);
+            const std::string evName = meta.empty() ? std::to_string(e) : meta[s].eventID;
+            if (meta.empty())
+                mp.AddFrames(evName, c, frames, 10000);
+            else
+                mp.AddNamedFrames(evName, c, meta[s].names, &frames);
             Trainer t(c, {}, "", "cam%d_image%u.png", "", mp.clone(), false);
             t.TrainedAvgImage.create(H, W, CV_8U);
             t.TrainedSigmaImage.create(H, W, CV_8U);
@@ -531,7 +568,7 @@ private:
             t.TrainingSetSize = tss[c];
             t.ModelId = 0; // always (re)uploaded
             Trainer *tp = &t;
-            L3Localizer A(std::to_string(e), "", c, true, &tp, maskDir, mp.clone());
+            L3Localizer A(evName, "", c, true, &tp, maskDir, mp.clone());
             int staged = 0;
             do {
                 A.FindTriggerFrame(true, A.MatTrigFrame + 1);
@@ -592,8 +629,15 @@ private:
             StackState &st_ = stacks[s];
             const int e = s / C, c = s % C;
             Trainer *t = trainers[c];
-            st_.analyzer.reset(new L3Localizer(std::to_string(e), "", c, true, &t, maskDir, parser.clone()));
-            st_.data.F = F;
+            if (meta.empty()) {
+                st_.analyzer.reset(new L3Localizer(std::to_string(e), "", c, true, &t, maskDir, parser.clone()));
+                st_.data.F = F;
+                st_.data.ok = nullptr;
+            } else {
+                st_.analyzer.reset(new L3Localizer(meta[s].eventID, "", c, true, &t, maskDir, metaParser.clone()));
+                st_.data.F = (int)meta[s].names.size();
+                st_.data.ok = meta[s].ok.data();
+            }
             st_.data.W = W;
             st_.data.H = H;
             st_.data.refOffset = tss[c] < 6 ? 1 : 2;
@@ -663,6 +707,7 @@ private:
                 st_.done = true;
                 return;
             }
+            const int F = st_.data.F;       // this stack's frame count (<= the pipeline's)
             if (F <= 5) { // LocalizeOMatic refuses (L3Localizer.cpp:889) -> -8
                 A->LocalizeOMatic("");
                 st_.staged = -8;
@@ -837,6 +882,288 @@ private:
         }
     }
 };
+
+// ------------------------------------------------------------------------------------------------------------------
+// RunBatched: a run from a Parser through the batched pipeline (see runbatch.hpp).  Replaces the detect loop of the
+// reference's main program (AutoBubStart3.cpp:338-388): same per-(event, camera) analyses, same output blocks in the
+// same order, but the frames of a whole batch of events are decoded once (the reference decodes a frame up to three
+// times: main loop, look-ahead, localizer), uploaded once and processed with a handful of launches.
+// ------------------------------------------------------------------------------------------------------------------
+int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const std::vector<Trainer *> &Trainers,
+               int numCams, const std::string &out_dir, const std::string &run_number, int frameOffset,
+               const BatchedRunOptions &opt, BatchedRunStats *stats, std::string *why)
+{
+    const double tAll = nowMs();
+    auto refuse = [&](const char *msg) {
+        if (why)
+            *why = msg;
+        return 1;
+    };
+    const int C = numCams;
+    if (C <= 0 || (int)Trainers.size() != C)
+        return refuse("one trainer per camera expected");
+    const int W = Trainers[0]->TrainedAvgImage.cols, H = Trainers[0]->TrainedAvgImage.rows;
+    if (W <= 0 || H <= 0)
+        return refuse("untrained model");
+    for (Trainer *t : Trainers)
+        if (t->TrainedAvgImage.cols != W || t->TrainedAvgImage.rows != H || t->TrainedSigmaImage.cols != W ||
+            t->TrainedSigmaImage.rows != H)
+            return refuse("cameras with different image sizes");
+    const size_t P = (size_t)W * H;
+    std::vector<int> mine; // indices into EventList handled by this process
+    for (int i = 0; i < (int)EventList.size(); ++i)
+        if (opt.shardWorld <= 1 || i % opt.shardWorld == opt.shardRank)
+            mine.push_back(i);
+    BatchedRunStats st;
+    st.W = W;
+    st.H = H;
+    st.events = (int)mine.size();
+    if (mine.empty()) {
+        if (stats)
+            *stats = st;
+        return 0;
+    }
+    const int ndec = std::max(1, opt.decodeThreads);
+
+    // ---- frame lists of every (event, camera), in the Parser's (lexicographic) order -------------------------------
+    double t0 = nowMs();
+    std::vector<std::vector<std::vector<std::string>>> lists(mine.size(), std::vector<std::vector<std::string>>(C));
+    {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < std::min<int>(ndec, (int)mine.size()); ++t)
+            th.emplace_back([&]() {
+                std::unique_ptr<Parser> p(parser->clone());
+                for (;;) {
+                    const size_t k = next.fetch_add(1);
+                    if (k >= mine.size())
+                        break;
+                    for (int c = 0; c < C; ++c)
+                        p->ParseAndSortFramesInFolder(EventList[mine[k]], c, lists[k][c]);
+                }
+            });
+        for (auto &t : th)
+            t.join();
+    }
+    int Fmax = 1;
+    for (auto &ev : lists)
+        for (auto &l : ev)
+            Fmax = std::max(Fmax, (int)l.size());
+    st.list_s = (nowMs() - t0) * 1e-3;
+    if (Fmax > 1024)
+        return refuse("more than 1024 frames in one stack");
+    st.Fmax = Fmax;
+    const size_t perEvent = (size_t)C * Fmax * P;
+    int G = (int)std::max<size_t>(1, std::min<size_t>(opt.batchBytes / perEvent, mine.size()));
+    G = std::min(G, 512);
+    const int nb = ((int)mine.size() + G - 1) / G;
+    int ndev = 0;
+    HIPOK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0)
+        throw std::runtime_error("RunBatched: no GPU");
+    const int ngpus = std::max(1, std::min(opt.ngpus, nb));
+    st.gpus = ngpus;
+    st.batches = nb;
+    st.eventsPerBatch = G;
+
+    std::mutex turnMu;
+    std::condition_variable turnCv;
+    int turn = 0;       // next batch to be written (output is in event order, AutoBubStart3.cpp:380-383)
+    bool failed = false;
+    std::vector<std::string> errors(ngpus);
+    std::mutex statMu;
+
+    struct Decoded {
+        std::vector<StackMeta> meta;
+        double ms = 0;
+        long long ok = 0, bad = 0;
+    };
+    auto decodeBatch = [&](int b, uint8_t *h, Decoded &out, int nthreads) {
+        const double td = nowMs();
+        const int e0 = b * G, nEv = std::min(G, (int)mine.size() - e0);
+        out.meta.assign((size_t)G * C, StackMeta());
+        std::vector<std::pair<int, int>> tasks;
+        for (int k = 0; k < G; ++k)
+            for (int c = 0; c < C; ++c) {
+                StackMeta &m = out.meta[(size_t)k * C + c];
+                if (k < nEv) {
+                    m.eventID = EventList[mine[e0 + k]];
+                    m.names = lists[e0 + k][c];
+                    m.ok.assign(m.names.size(), 0);
+                    for (int f = 0; f < (int)m.names.size(); ++f)
+                        tasks.emplace_back(k * C + c, f);
+                } else
+                    m.eventID = "_pad" + std::to_string(k); // filler of the last batch: no frames -> -9, never written
+            }
+        std::atomic<size_t> next{0};
+        std::atomic<long long> good{0}, bad{0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < std::max(1, std::min<int>(nthreads, (int)tasks.size())); ++t)
+            th.emplace_back([&]() {
+                std::unique_ptr<Parser> p(parser->clone());
+                for (;;) {
+                    const size_t i = next.fetch_add(1);
+                    if (i >= tasks.size())
+                        break;
+                    const int s = tasks[i].first, f = tasks[i].second;
+                    StackMeta &m = out.meta[s];
+                    cv::Mat img;
+                    int rc = -1;
+                    try {
+                        rc = p->GetImage(m.eventID, m.names[f], img);
+                    } catch (...) {
+                        rc = -1;
+                    }
+                    // (-1 or an empty image = undecodable, like EventOnDevice; so is a frame of another size)
+                    if (rc == -1 || img.empty() || img.cols != W || img.rows != H) {
+                        ++bad;
+                        continue;
+                    }
+                    std::memcpy(h + ((size_t)s * Fmax + f) * P, img.data, P);
+                    m.ok[f] = 1;
+                    ++good;
+                }
+            });
+        for (auto &t : th)
+            t.join();
+        out.ok = good;
+        out.bad = bad;
+        out.ms = nowMs() - td;
+    };
+
+    auto writeBatch = [&](RunPipeline &pipe, int b) {
+        const int e0 = b * G, nEv = std::min(G, (int)mine.size() - e0);
+        for (int k = 0; k < nEv; ++k) {
+            OutputWriter out(out_dir, run_number, frameOffset, C);
+            const int actualEventNumber = atoi(EventList[mine[e0 + k]].c_str());
+            std::vector<std::vector<bubble *>> owned(C);
+            for (int c = 0; c < C; ++c) {
+                StackState &ss = pipe.stacks[(size_t)k * C + c];
+                if (!ss.error.empty())
+                    std::cout << ss.error << '\n'; // (AnyCamAnalysis prints the exception text, then stages -6)
+                if (ss.staged == 0) {
+                    for (BubbleOut &bo : ss.bubbles) { // the analyzers are gone: rebuild the track records
+                        bubble *bb = new bubble(bo.desc[0]);
+                        for (size_t d = 1; d < bo.desc.size(); ++d) {
+                            bb->lockThisIteration = false;
+                            *bb << bo.desc[d];
+                        }
+                        owned[c].push_back(bb);
+                    }
+                    out.stageCameraOutput(owned[c], c, ss.trig, actualEventNumber);
+                } else
+                    out.stageCameraOutputError(c, ss.staged, actualEventNumber);
+            }
+            out.writeCameraOutput();
+            for (auto &l : owned)
+                for (bubble *bb : l)
+                    delete bb;
+        }
+    };
+
+    auto worker = [&](int g) {
+        uint8_t *h_slab[2] = {nullptr, nullptr}, *d_slab[2] = {nullptr, nullptr}, *d_model = nullptr;
+        hipStream_t copyStream = nullptr;
+        std::thread dec;
+        try {
+            const int dev = (opt.firstDevice + g) % ndev;
+            HIPOK(hipSetDevice(dev));
+            const size_t slabBytes = (size_t)G * perEvent;
+            const int nslots = g + ngpus < nb ? 2 : 1; // a worker with a single batch needs no second buffer
+            for (int k = 0; k < nslots; ++k) {
+                HIPOK(hipHostMalloc((void **)&h_slab[k], slabBytes, hipHostMallocDefault));
+                HIPOK(hipMalloc((void **)&d_slab[k], slabBytes));
+            }
+            HIPOK(hipMalloc((void **)&d_model, 3 * (size_t)C * P)); // mu | sigma | sigma6
+            uint8_t *d_mu = d_model, *d_sigma = d_model + (size_t)C * P, *d_s6 = d_model + 2 * (size_t)C * P;
+            HIPOK(hipStreamCreateWithFlags(&copyStream, hipStreamNonBlocking));
+            std::vector<int> tss(C);
+            for (int c = 0; c < C; ++c) {
+                HIPOK(hipMemcpy(d_mu + (size_t)c * P, Trainers[c]->TrainedAvgImage.data, P, hipMemcpyHostToDevice));
+                HIPOK(hipMemcpy(d_sigma + (size_t)c * P, Trainers[c]->TrainedSigmaImage.data, P, hipMemcpyHostToDevice));
+                tss[c] = Trainers[c]->TrainingSetSize;
+            }
+            check(abub_sigma6_dev(d_sigma, d_s6, (size_t)C * P, copyStream), "abub_sigma6_dev");
+            HIPOK(hipStreamSynchronize(copyStream));
+            RunPipeline pipe(dev, W, H, Fmax, G, C, tss.data(), std::max(1, opt.hostThreads), opt.maskDir.c_str());
+            pipe.d_sigmaRaw = d_sigma;
+            const int nthr = std::max(1, ndec / ngpus);
+            Decoded decd[2];
+            int slot = 0;
+            if (g < nb)
+                dec = std::thread([&, slot]() { decodeBatch(g, h_slab[slot], decd[slot], nthr); });
+            for (int b = g; b < nb; b += ngpus) {
+                dec.join();
+                const int bn = b + ngpus;
+                if (bn < nb) {
+                    const int ns = slot ^ 1;
+                    dec = std::thread([&, bn, ns]() { decodeBatch(bn, h_slab[ns], decd[ns], nthr); });
+                }
+                const int nEv = std::min(G, (int)mine.size() - b * G);
+                const double tg = nowMs();
+                HIPOK(hipMemcpyAsync(d_slab[slot], h_slab[slot], (size_t)nEv * perEvent, hipMemcpyHostToDevice, copyStream));
+                const double dms = decd[slot].ms;
+                const long long good = decd[slot].ok, bad = decd[slot].bad;
+                pipe.setStackMeta(std::move(decd[slot].meta));
+                pipe.run(d_slab[slot], d_mu, d_s6, copyStream); // waits for the upload first
+                const double gms = nowMs() - tg;
+                double wms = 0;
+                {
+                    std::unique_lock<std::mutex> lock(turnMu);
+                    turnCv.wait(lock, [&] { return turn == b || failed; });
+                    if (failed)
+                        break;
+                    const double tw = nowMs();
+                    writeBatch(pipe, b);
+                    wms = nowMs() - tw;
+                    ++turn;
+                }
+                turnCv.notify_all();
+                {
+                    std::lock_guard<std::mutex> lock(statMu);
+                    st.decode_s += dms * 1e-3;
+                    st.gpu_s += gms * 1e-3;
+                    st.write_s += wms * 1e-3;
+                    st.frames += good;
+                    st.framesFailed += bad;
+                }
+                slot ^= 1;
+            }
+        } catch (std::exception &e) {
+            errors[g] = e.what();
+            {
+                std::lock_guard<std::mutex> lock(turnMu);
+                failed = true;
+            }
+            turnCv.notify_all();
+        }
+        if (dec.joinable())
+            dec.join();
+        if (copyStream)
+            (void)hipStreamDestroy(copyStream);
+        for (int k = 0; k < 2; ++k) {
+            if (h_slab[k])
+                (void)hipHostFree(h_slab[k]);
+            if (d_slab[k])
+                (void)hipFree(d_slab[k]);
+        }
+        if (d_model)
+            (void)hipFree(d_model);
+    };
+    std::vector<std::thread> th;
+    for (int g = 1; g < ngpus; ++g)
+        th.emplace_back(worker, g);
+    worker(0);
+    for (auto &t : th)
+        t.join();
+    for (const std::string &e : errors)
+        if (!e.empty())
+            throw std::runtime_error("RunBatched: " + e);
+    st.total_s = (nowMs() - tAll) * 1e-3;
+    if (stats)
+        *stats = st;
+    return 0;
+}
 
 } // namespace abub
 

@@ -52,6 +52,10 @@ public:
     // frames are named cam<c>_image<k>.png with zero-free numbering starting at `firstIndex`;
     // the list is kept in lexicographic name order like the real parsers.
     void AddFrames(const std::string &EventID, int camera, const std::vector<cv::Mat> &frames, int firstIndex = 30);
+    // the same with the names given (a batched driver registers the real frame names of a run; `images` may be
+    // NULL when the pixels only live in HBM)
+    void AddNamedFrames(const std::string &EventID, int camera, const std::vector<std::string> &names,
+                        const std::vector<cv::Mat> *images = nullptr);
 
     Parser *clone() override { return new MemParser(*this); }
     int GetImage(std::string EventID, std::string FrameName, cv::Mat &out) override;

@@ -49,22 +49,28 @@ def test_empty_run_fails_training_with_minus7(tmp_path):
     assert rc == 249 and "Failed to train" in out  # -7
 
 
-@pytest.mark.gpu
-def test_cli_run_matches_oracle_text(tmp_path, oracle):
-    W, H, F, ncams, nev = 320, 128, 41, 2, 5
-    run_id = "20200925_1"
+def _make_run(tmp_path, oracle, W=320, H=128, F=41, ncams=2, nev=5, run_id="20200925_1"):
+    """A synthetic run on disk (PNG frames) with two irregular stacks -- event 3 / cam 1 has an undecodable frame 7
+    (before any bubble: status -9), event 4 / cam 0 has only 20 frames -- and the oracle's recon text for it."""
     rd = os.path.join(tmp_path, "data", run_id)
-    stacks = {}
+    stacks, ok = {}, {}
     for e in range(nev):
         for c in range(ncams):
             spec = synth.random_spec(W, H, F, 900 + e, c, p_none=0.2, margin=20)
             st = synth.render_event(W, H, spec, 900 + e, c)
+            if (e, c) == (4, 0):
+                st = st[:20]
             stacks[(e, c)] = st
+            ok[(e, c)] = np.ones(len(st), np.uint8)
             d = os.path.join(rd, str(e), "Images")
             os.makedirs(d, exist_ok=True)
-            for k in range(F):
-                Image.fromarray(st[k]).save(os.path.join(d, f"cam{c}_image{30 + k}.png"))
-    # expected text from the oracle: train on frames 0,1 of every event, then every (event, camera)
+            for k in range(len(st)):
+                path = os.path.join(d, f"cam{c}_image{30 + k}.png")
+                Image.fromarray(st[k]).save(path)
+                if (e, c, k) == (3, 1, 7):
+                    raw = open(path, "rb").read()
+                    open(path, "wb").write(raw[: len(raw) // 2])  # truncated file: GetImage == -1
+                    ok[(e, c)][k] = 0
     expected = oracle.format_header()
     models = []
     for c in range(ncams):
@@ -72,33 +78,58 @@ def test_cli_run_matches_oracle_text(tmp_path, oracle):
         assert all(oracle.pair_entropy16(stacks[(e, c)][1], stacks[(e, c)][0]) <= 0.0005 for e in range(nev))
         mu, sg = oracle.welford(tr)
         models.append((mu, sg, len(tr)))
+    blocks = []
     for e in range(nev):
         ans, staged = [], []
         for c in range(ncams):
-            a = oracle.Analyzer(stacks[(e, c)], *models[c])
+            a = oracle.Analyzer(stacks[(e, c)], *models[c], frame_ok=ok[(e, c)])
             staged.append(a.any_cam_analysis()[0])
             ans.append(a)
-        expected += oracle.format_event(ans, staged, run_id, e, 30)
+        blocks.append(oracle.format_event(ans, staged, run_id, e, 30))
         for a in ans:
             a.close()
-    out1 = os.path.join(tmp_path, "out_dir")
-    os.makedirs(out1)
-    rc, so, se = run_cli(["-d", os.path.join(tmp_path, "data"), "-r", run_id, "-o", out1, "-D", "40l-19"],
-                         env={"ABUB_THREADS": "4", "ABUB_NUM_CAMS": "2"})
-    assert rc == 0, (so[-2000:], se[-2000:])
-    assert open(os.path.join(out1, f"abub3hs_{run_id}.txt")).read() == expected
+    return rd, run_id, expected, blocks
+
+
+@pytest.mark.gpu
+def test_cli_run_matches_oracle_text(tmp_path, oracle):
+    rd, run_id, header, blocks = _make_run(tmp_path, oracle)
+    expected = header + "".join(blocks)
+    assert any("  -9  " in b for b in blocks)
+    data = os.path.join(tmp_path, "data")
+
+    def cli(tag, extra_args=(), env=None, zipped=False):
+        out = os.path.join(tmp_path, "out_" + tag)
+        os.makedirs(out)
+        e = {"ABUB_THREADS": "4", "ABUB_NUM_CAMS": "2"}
+        e.update(env or {})
+        rc, so, se = run_cli((["-z"] if zipped else []) + ["-d", data, "-r", run_id, "-o", out, "-D", "40l-19"] + list(extra_args), env=e)
+        assert rc == 0, (tag, so[-2000:], se[-2000:])
+        return open(os.path.join(out, f"abub3hs_{run_id}.txt")).read(), so
+
+    # default = the batched path (whole batches of events decoded into pinned memory, RunPipeline, ordered output)
+    txt, so = cli("batched")
+    assert "batched detect:" in so and txt == expected
+    # several small batches (the last one padded), two worker threads sharing the GPU
+    txt, so = cli("batched_small", ["--gpus", "2"], env={"ABUB_BATCH_MB": "4"})
+    assert "batched detect:" in so and txt == expected
+    # the reference's one-analyzer-at-a-time loop
+    txt, so = cli("per_event", ["--per-event"])
+    assert "batched detect" not in so and txt == expected
+    # events dealt to two shards (i % 2), each writes its own events in order
+    for r in (0, 1):
+        txt, _ = cli(f"shard{r}", ["--gpu-shard", f"{r}/2"])
+        assert txt == header + "".join(blocks[r::2]), r
     # same run as a zip archive
-    zpath = os.path.join(tmp_path, "data", run_id + ".zip")
+    zpath = os.path.join(data, run_id + ".zip")
     with zipfile.ZipFile(zpath, "w", zipfile.ZIP_DEFLATED) as z:
         for dp, dn, fn in os.walk(rd):
-            rel = os.path.relpath(dp, os.path.join(tmp_path, "data"))
+            rel = os.path.relpath(dp, data)
             z.writestr(rel + "/", b"")
             for f in sorted(fn):
                 z.write(os.path.join(dp, f), os.path.join(rel, f))
-    out2 = os.path.join(tmp_path, "out_zip")
-    os.makedirs(out2)
     os.rename(rd, rd + "_moved")  # make sure the zip is what gets read
-    rc, so, se = run_cli(["-z", "-d", os.path.join(tmp_path, "data"), "-r", run_id, "-o", out2, "-D", "40l-19"],
-                         env={"ABUB_THREADS": "2", "ABUB_NUM_CAMS": "2"})
-    assert rc == 0, (so[-2000:], se[-2000:])
-    assert open(os.path.join(out2, f"abub3hs_{run_id}.txt")).read() == expected
+    txt, so = cli("zip", zipped=True, env={"ABUB_THREADS": "2"})
+    assert "batched detect:" in so and txt == expected
+    txt, so = cli("zip_per_event", ["--per-event"], zipped=True, env={"ABUB_THREADS": "2"})
+    assert txt == expected

@@ -2,6 +2,7 @@
 // (BASELINE.json configs[2]: "Synthetic 10k-frame stack 1280x1024, fused diff+thresh+morph HBM-roofline
 // microbench").  Exists so that rocprofv3 --pmc can wrap a plain native program.
 //   k2_microbench [frames=2000] [reps=5] [store=0|1] [W=1280] [H=1024] [rows_per_chunk=0] [sigma=1] [chain=1]
+//                 [cycle=0]
 // (ABUB_K2_BOUND=0 in the environment: the plain row machine for every row, the dense-regime worst case)
 // Build: hipcc --offload-arch=gfx950 -O2 tools/k2_microbench.cpp -Iinclude -Lautobub3hs_amd -labub_hip
 #include <hip/hip_runtime.h>
@@ -21,7 +22,7 @@ __device__ inline uint32_t mix(uint32_t x)
     return x ^ (x >> 16);
 }
 // background + sum of four U{-1,0,1} per frame, sparse bright discs drifting every 64 frames
-__global__ void fill(uint8_t *slab, size_t P, int W, size_t total)
+__global__ void fill(uint8_t *slab, size_t P, int W, size_t total, int discs)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -33,7 +34,7 @@ __global__ void fill(uint8_t *slab, size_t P, int W, size_t total)
         int v = 40 + (x * 60) / W + (y % 97) / 4 + n;
         int k = (int)(f % 64);
         int dx = x - (200 + (int)((f / 64) * 37 % 800)), dy = y - (300 + (int)((f / 64) * 53 % 400));
-        if (k >= 32 && dx * dx + dy * dy <= (2 + k - 32) * (2 + k - 32))
+        if (discs && k >= 32 && dx * dx + dy * dy <= (2 + k - 32) * (2 + k - 32))
             v += 40;
         slab[i] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
     }
@@ -46,6 +47,9 @@ int main(int argc, char **argv)
     int R = argc > 6 ? atoi(argv[6]) : 0;
     int chain = argc > 8 ? atoi(argv[8]) : 1; // 1: pass the chain hint (jobs f, f+2 share a frame), 0: plain job list
     int sig = argc > 7 ? atoi(argv[7]) : 1; // model sigma: 1 -> ~3.5 supra-threshold noise pixels per row, 2 -> none
+    int discs = argc > 10 ? atoi(argv[10]) : 1; // 0: noise only (no growing discs)
+    int cyc = argc > 9 ? atoi(argv[9]) : 0; // > 0: the jobs cycle through the first `cyc` frames only (L2-resident inputs:
+                                            // what the kernel costs when memory is free)
     size_t P = (size_t)W * H;
     uint8_t *slab, *sigma, *sigma6, *diff = nullptr;
     uint32_t *hist;
@@ -58,12 +62,13 @@ int main(int argc, char **argv)
     CK(hipMalloc(&jobs, (size_t)njobs * sizeof(abub_job)));
     if (store)
         CK(hipMalloc(&diff, P * (size_t)njobs));
-    hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, slab, P, W, P * F);
+    hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, slab, P, W, P * F, discs);
     CK(hipMemset(sigma, sig, P));
     AK(abub_sigma6_dev(sigma, sigma6, P, nullptr));
     std::vector<abub_job> hj(njobs);
     for (int j = 0; j < njobs; j++)
-        hj[j] = abub_job{(uint32_t)(j + 2), (uint32_t)j, 0u, (uint32_t)j};
+        hj[j] = cyc > 0 ? abub_job{(uint32_t)((j + 2) % cyc), (uint32_t)(j % cyc), 0u, (uint32_t)j}
+                        : abub_job{(uint32_t)(j + 2), (uint32_t)j, 0u, (uint32_t)j};
     CK(hipMemcpy(jobs, hj.data(), njobs * sizeof(abub_job), hipMemcpyHostToDevice));
     CK(hipDeviceSynchronize());
     hipEvent_t a, b;
@@ -98,7 +103,7 @@ int main(int argc, char **argv)
     printf("{\"frames\": %d, \"W\": %d, \"H\": %d, \"store\": %d, \"chain\": %d, \"sigma\": %d, \"ms_avg\": %.4f, \"ms_min\": %.4f, "
            "\"frames_per_s\": %.1f, \"compulsory_GBps\": %.1f, \"frac_of_8TBps\": %.4f, \"alg_GBps\": %.1f, \"nonzero_px\": %llu, "
            "\"hist_total_ok\": %d}\n",
-           njobs, W, H, store, chain, sig, ms, best, njobs / (ms * 1e-3), comp / (ms * 1e-3) / 1e9, comp / (ms * 1e-3) / 1e9 / 8000.0,
+           njobs, W, H, store, chain, sig, cyc, ms, best, njobs / (ms * 1e-3), comp / (ms * 1e-3) / 1e9, comp / (ms * 1e-3) / 1e9 / 8000.0,
            bytes / (ms * 1e-3) / 1e9, nz, tot == (unsigned long long)P * njobs);
     return 0;
 }

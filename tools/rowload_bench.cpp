@@ -223,6 +223,46 @@ __global__ __launch_bounds__(64) void rd_chain(const uint8_t *__restrict__ frame
     if (acc == 0x12345678u) out[unit] = acc;
 }
 
+// the chain2 pattern at a fixed occupancy (waves per SIMD), to separate "not enough loads in flight" from bandwidth;
+// VALU = extra dependent-free VALU instructions per loaded dword (stand-in for the scan's arithmetic)
+template <int W, int MAP, int OCC, int VALU>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void rd_chain_occ(const uint8_t *__restrict__ frames, const uint8_t *__restrict__ sg, int H, int R,
+                                               int nchunks, uint32_t *out)
+{
+    using M = RowMap<W, MAP>;
+    constexpr int K = 2;
+    const int lane = threadIdx.x, unit = blockIdx.x, ch = unit / nchunks, chunk = unit - ch * nchunks;
+    const size_t P = (size_t)W * H;
+    const int base = (ch / 2) * 2 * K + (ch & 1);
+    const int y0 = chunk * R;
+    int y1 = y0 + R; if (y1 > H) y1 = H;
+    uint32_t acc = 0;
+    uint32_t buf[2][K + 2][M::N];
+    auto load = [&](int slot, int y) {
+        const size_t o = (size_t)(y < H ? y : H - 1) * W;
+#pragma unroll
+        for (int f = 0; f <= K; f++) M::load(buf[slot][f], frames + (size_t)(base + 2 * f) * P + o, lane);
+        M::load(buf[slot][K + 1], sg + o, lane);
+    };
+    load(0, y0);
+    for (int y = y0; y < y1; y += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            load(u ^ 1, y + u + 1);
+#pragma unroll
+            for (int f = 0; f < K + 2; f++)
+#pragma unroll
+                for (int d = 0; d < M::N; d++) {
+                    uint32_t v = buf[u][f][d];
+#pragma unroll
+                    for (int q = 0; q < VALU; q++) v = __builtin_amdgcn_perm(v, acc, 0x07020500u + q); // slow-rate op
+                    acc |= v + (uint32_t)f;
+                }
+        }
+    }
+    if (acc == 0x12345678u) out[unit] = acc;
+}
+
 static hipEvent_t e0, e1;
 template <typename F>
 static float timeit(F launch, int reps)
@@ -284,6 +324,19 @@ int main(int argc, char **argv)
     CK(hipMemset(sg, 2, Pmax));
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
+    {
+        const int H = 1024, Rr = R > 0 ? R : 128, nch = (H + Rr - 1) / Rr, njobs = F - 2, nchains = (njobs / 4) * 2;
+#define OCCRUN(MAP, OCC, VALU)                                                                                                   \
+    {                                                                                                                            \
+        float ms = timeit([&] { hipLaunchKernelGGL((rd_chain_occ<1280, MAP, OCC, VALU>), dim3(nchains * nch), dim3(64), 0, 0, slab, sg, H, Rr, nch, out); }, 5); \
+        printf("{\"W\": 1280, \"map\": %d, \"pattern\": \"chain2@occ\", \"occ\": %d, \"valu_per_dword\": %d, \"ms\": %.4f, \"us_per_job\": %.4f}\n", MAP, OCC, VALU, ms, 1e3 * ms / (nchains * 2)); \
+    }
+        OCCRUN(0, 2, 0) OCCRUN(0, 3, 0) OCCRUN(0, 4, 0) OCCRUN(0, 6, 0) OCCRUN(0, 8, 0)
+        OCCRUN(1, 2, 0) OCCRUN(1, 3, 0) OCCRUN(1, 4, 0) OCCRUN(1, 6, 0) OCCRUN(1, 8, 0)
+        OCCRUN(0, 4, 2) OCCRUN(0, 4, 4) OCCRUN(0, 4, 6) OCCRUN(0, 4, 8) OCCRUN(0, 8, 4) OCCRUN(0, 8, 6)
+        OCCRUN(1, 4, 4) OCCRUN(1, 4, 6)
+    }
+    if (argc > 3) return 0;
     run<1280, 0>(slab, sg, out, diff, F, 1024, R);
     run<1280, 1>(slab, sg, out, diff, F, 1024, R);
     run<1280, 2>(slab, sg, out, diff, F, 1024, R);
