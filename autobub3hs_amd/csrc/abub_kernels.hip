@@ -1672,47 +1672,50 @@ __global__ __launch_bounds__(256) void k3_generic(const uint8_t *__restrict__ fr
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3 fast: register-rolling rows, same lane mapping as K2.  O = sat(|f-mu| - sigma6) on u16 pairs,
-// horizontal 3-tap via one alignbit per pair, vertical 3-tap as two in-place accumulators,
-// (S+4)/9 as ((S+4)*7282)>>16 (exact for S <= 2295, checked exhaustively in tests/test_k3_div9),
-// LDS histogram and fused compaction in the rare non-zero path, optional image store.
+// K3 fast: register-rolling rows, same lane mapping as K2.  O = sat(|f - mu| - sigma6) as
+//     O = sat(f - HI) | sat(LO - f),   HI = mu + sigma6,   LO = sat(mu - sigma6)        (L3Localizer.cpp:779-782)
+// on u16 pairs (at most one of the two terms is non-zero; HI needs no clamp: f <= 255 < 256 <= HI whenever it would
+// saturate).  Two kernels, like K2's bound-and-verify:
+//   k3_bound_scan A tracking frame differs from its camera's mean by more than 6 sigma only where a bubble is (and
+//                 at the odd hot pixel), so almost every output pixel of the 3x3 box is zero.  One wave scans the
+//                 rows of a chunk for KF consecutive jobs that share their model (the tracking frames of a stack):
+//                 mu / sigma6 rows are loaded and turned into HI / LO once for all KF frames -- (KF + 2) / KF row
+//                 streams per frame instead of 3 -- and proves rows zero from a bound on the box sums (see the
+//                 kernel); suspect groups are computed exactly by the same wave, dense chunks are handed over.
+//   k3_rows       the row machine -- horizontal 3-tap via one alignbit per pair, vertical 3-tap as two in-place
+//                 accumulators, (S+4)/9 as ((S+4)*7282)>>16 (exact for S <= 2295, checked exhaustively in tests),
+//                 LDS histogram and fused compaction in the rare non-zero path, optional image store -- on whole
+//                 chunks (K3 without the scan: ABUB_K3_SCAN=0, or jobs the scan cannot group) or on listed pieces.
 // ------------------------------------------------------------------------------------------------
-template <int NDW>
-struct Row3In {
-    uint32_t f[NDW], m[NDW], s[NDW];
-};
 
 template <int NDW>
-__device__ __forceinline__ void k3_load_row(Row3In<NDW> &R, const uint8_t *__restrict__ f,
-                                            const uint8_t *__restrict__ m, const uint8_t *__restrict__ sg,
-                                            int y, int W, int xoff)
+__device__ __forceinline__ void k3_thresholds(const uint32_t (&mraw)[NDW], const uint32_t (&sraw)[NDW], uint32_t (&HI)[2 * NDW],
+                                              uint32_t (&LO)[2 * NDW])
 {
-    size_t o = (size_t)y * W + xoff;
-    const uint32_t *pf = reinterpret_cast<const uint32_t *>(f + o);
-    const uint32_t *pm = reinterpret_cast<const uint32_t *>(m + o);
-    const uint32_t *ps = reinterpret_cast<const uint32_t *>(sg + o);
 #pragma unroll
     for (int d = 0; d < NDW; d++) {
-        R.f[d] = pf[d];
-        R.m[d] = pm[d];
-        R.s[d] = ps[d];
+        const uint32_t m0 = widen_lo(mraw[d]), m1 = widen_hi(mraw[d]);
+        const uint32_t s0 = widen_lo(sraw[d]), s1 = widen_hi(sraw[d]);
+        HI[2 * d] = m0 + s0;
+        HI[2 * d + 1] = m1 + s1;
+        LO[2 * d] = pk_subsat(m0, s0);
+        LO[2 * d + 1] = pk_subsat(m1, s1);
     }
 }
 
 template <int NDW, bool STORE>
-__device__ __forceinline__ void k3_row(const Row3In<NDW> &in, uint32_t (&a0)[2 * NDW], uint32_t (&xp)[2 * NDW],
-                                       bool emit, bool active, bool first_lane, bool last_lane, uint32_t *lh,
-                                       uint32_t *__restrict__ po, const Compact &cp, uint32_t pix0, int &zrun)
+__device__ __forceinline__ void k3_row(const uint32_t (&fr)[NDW], const uint32_t (&HI)[2 * NDW], const uint32_t (&LO)[2 * NDW],
+                                       uint32_t (&a0)[2 * NDW], uint32_t (&xp)[2 * NDW], bool emit, bool active,
+                                       bool first_lane, bool last_lane, uint32_t *lh, uint32_t *__restrict__ po,
+                                       const Compact &cp, uint32_t pix0, int &zrun)
 {
     constexpr int NP = 2 * NDW;
     uint32_t X[NP];
 #pragma unroll
     for (int d = 0; d < NDW; d++) {
-        uint32_t f0 = widen_lo(in.f[d]), f1 = widen_hi(in.f[d]);
-        uint32_t m0 = widen_lo(in.m[d]), m1 = widen_hi(in.m[d]);
-        uint32_t s0 = widen_lo(in.s[d]), s1 = widen_hi(in.s[d]);
-        X[2 * d] = pk_subsat(pk_subsat(f0, m0) | pk_subsat(m0, f0), s0);     // L3Localizer.cpp:779-782
-        X[2 * d + 1] = pk_subsat(pk_subsat(f1, m1) | pk_subsat(m1, f1), s1);
+        const uint32_t f0 = widen_lo(fr[d]), f1 = widen_hi(fr[d]);
+        X[2 * d] = pk_subsat(f0, HI[2 * d]) | pk_subsat(LO[2 * d], f0);
+        X[2 * d + 1] = pk_subsat(f1, HI[2 * d + 1]) | pk_subsat(LO[2 * d + 1], f1);
     }
     // zero-run shortcut (wave-uniform, as in K2): two all-zero rows drain a0 and xp; from then on an all-zero row
     // changes nothing and emits (0 + 4) / 9 = 0
@@ -1797,92 +1800,442 @@ __device__ __forceinline__ void k3_row(const Row3In<NDW> &in, uint32_t (&a0)[2 *
     }
 }
 
+// Whole chunks (unit = block: job * nchunks + chunk) or, in list mode, the pieces {job, y0 | y1 << 16} of k3_bound_scan.
 template <int NDW, bool STORE>
 __global__ __launch_bounds__(64) void k3_rows(const uint8_t *__restrict__ frames, const uint8_t *__restrict__ mu,
                                               const uint8_t *__restrict__ sigma6,
                                               const abub_job *__restrict__ jobs, int W, int H,
                                               int rows_per_chunk, int nchunks, uint32_t *__restrict__ hist,
                                               uint8_t *__restrict__ img, const int32_t *__restrict__ cthr,
-                                              uint32_t *pairs, uint32_t pcap, uint32_t *pcount, uint32_t slot_base)
+                                              uint32_t *pairs, uint32_t pcap, uint32_t *pcount, uint32_t slot_base,
+                                              const uint2 *__restrict__ piece_list, const uint32_t *__restrict__ piece_count)
 {
     constexpr int NP = 2 * NDW;
     __shared__ uint32_t lh[256];
     const int lane = threadIdx.x;
-    const int unit = blockIdx.x;
-    const int job = unit / nchunks;
-    const int chunk = unit - job * nchunks;
-    const abub_job jb = jobs[job];
     const size_t P = (size_t)W * H;
-    const uint8_t *f = frames + (size_t)jb.cur * P;
-    const uint8_t *m = mu + (size_t)jb.model * P;
-    const uint8_t *sg = sigma6 + (size_t)jb.model * P;
     const int nl = W / (4 * NDW);
     const bool active = lane < nl;
     const bool first_lane = lane == 0, last_lane = lane == nl - 1;
     const int xoff = active ? lane * 4 * NDW : 0;
+    const uint32_t nunits_ = piece_list ? *piece_count : gridDim.x;
+    for (uint32_t ui = blockIdx.x; ui < nunits_; ui += gridDim.x) {
+        int job, y0, y1;
+        if (piece_list) {
+            job = (int)piece_list[ui].x;
+            y0 = (int)(piece_list[ui].y & 0xffffu);
+            y1 = (int)(piece_list[ui].y >> 16);
+        } else {
+            job = (int)ui / nchunks;
+            const int chunk = (int)ui - job * nchunks;
+            y0 = chunk * rows_per_chunk;
+            y1 = y0 + rows_per_chunk;
+        }
+        if (y1 > H)
+            y1 = H;
+        const abub_job jb = jobs[job];
+        const uint8_t *f = frames + (size_t)jb.cur * P;
+        const uint8_t *m = mu + (size_t)jb.model * P;
+        const uint8_t *sg = sigma6 + (size_t)jb.model * P;
+        const int T = y1 - y0 + 2; // input rows y0-1 .. y1 (reflected)
+
+        lh[lane] = 0;
+        lh[lane + 64] = 0;
+        lh[lane + 128] = 0;
+        lh[lane + 192] = 0;
+        __syncthreads();
+
+        uint32_t a0[NP], xp[NP];
+#pragma unroll
+        for (int j = 0; j < NP; j++)
+            a0[j] = xp[j] = 0;
+        uint8_t *obase = STORE ? img + (size_t)jb.out * P + xoff : nullptr;
+        Compact cp;
+        cp.pairs = cthr ? pairs : nullptr;
+        cp.count = pcount;
+        cp.cap = pcap;
+        cp.slot = jb.out + slot_base;
+        cp.thr = cthr ? cthr[jb.out] : 255;
+
+        uint32_t raw[2][3][NDW]; // frame, mu, sigma6
+#define K3_LOAD(SL, Y)                                                                        \
+    {                                                                                         \
+        const size_t o_ = (size_t)(Y) * W + xoff;                                             \
+        const uint32_t *pf_ = reinterpret_cast<const uint32_t *>(f + o_);                     \
+        const uint32_t *pm_ = reinterpret_cast<const uint32_t *>(m + o_);                     \
+        const uint32_t *ps_ = reinterpret_cast<const uint32_t *>(sg + o_);                    \
+        _Pragma("unroll") for (int d = 0; d < NDW; d++)                                       \
+        {                                                                                     \
+            raw[SL][0][d] = pf_[d];                                                           \
+            raw[SL][1][d] = pm_[d];                                                           \
+            raw[SL][2][d] = ps_[d];                                                           \
+        }                                                                                     \
+    }
+        K3_LOAD(0, reflect101(y0 - 1, H));
+        int zrun = 2; // the vertical state starts out all zero
+        for (int t = 0; t < T; t += 2) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int tt = t + u;
+                if (tt < T) {
+                    const int tn = tt + 1 < T ? tt + 1 : T - 1;
+                    K3_LOAD(u ^ 1, reflect101(y0 - 1 + tn, H));
+                    uint32_t HI[NP], LO[NP];
+                    k3_thresholds<NDW>(raw[u][1], raw[u][2], HI, LO);
+                    const int y = y0 + tt - 2;
+                    k3_row<NDW, STORE>(raw[u][0], HI, LO, a0, xp, tt >= 2, active, first_lane, last_lane, lh,
+                                       reinterpret_cast<uint32_t *>(obase + (ptrdiff_t)y * W), cp, (uint32_t)(y * W + xoff),
+                                       zrun);
+                }
+            }
+        }
+#undef K3_LOAD
+        __syncthreads();
+        uint32_t *gh = hist + (size_t)jb.out * 256;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t v = lh[lane + 64 * q];
+            if (v && (lane + 64 * q))
+                atomicAdd(&gh[lane + 64 * q], v);
+        }
+        __syncthreads(); // lh is zeroed again by the next unit
+    }
+}
+
+// The K3 scan ("bound and verify", like K2's): KF consecutive jobs per wave, sharing the model rows.
+// O(y,x) != 0 needs a 3x3 sum S >= 5.  With the lane's pixels in 4-column groups taken in pairs (as in k2b_row), the
+// box sums that touch a pair's columns in one row are bounded by M = left group + own pair + right group (edge groups
+// replicated: the reflected column lies inside them), and S <= M(y-1) + M(y) + M(y+1).  Rows where no pair reaches 5
+// are proven zero with one ballot (isolated hot pixels -- sigma = 0 leaves |f - mu| of a few ADU -- stay far below).
+// Suspect groups are remembered in LDS and computed exactly by the same wave afterwards (k3s_tail); a chunk with
+// too many of them (the bubble itself) hands its remaining rows to the row machine in pieces of K2B_SUB rows.
+#define K3S_PEND 256 /* suspects per (job, chunk) kept in LDS */
+
+template <int NDW>
+struct K3ScanJob {
+    static constexpr int GS = K2B_GS > NDW ? NDW : K2B_GS;
+    static constexpr int NG = (NDW + GS - 1) / GS;
+    uint32_t Mh[2][NG]; // M of the last two input rows, by row parity (the row loops are unrolled by two)
+    uint32_t npend, hot;
+    int handover; // < 0: scanning; >= 0: first output row left to the row machine
+};
+
+// exact O for the four pixels of every remembered group (L3Localizer.cpp:779-785): one lane per group
+template <bool COMPACT, bool STORE>
+__device__ __forceinline__ void k3s_tail(const uint32_t *pend, uint32_t npend, const abub_job jb, const uint8_t *__restrict__ frames,
+                                         const uint8_t *__restrict__ mu, const uint8_t *__restrict__ sigma6, int W, int H,
+                                         uint32_t *__restrict__ hist, uint8_t *__restrict__ img, const Compact &cp, int lane)
+{
+    if (npend == 0)
+        return;
+    __syncthreads(); // (one wave: orders the LDS writes of the scan before the reads below)
+    const size_t P = (size_t)W * H;
+    const uint32_t ngroups = (uint32_t)W / 4;
+    const uint8_t *f = frames + (size_t)jb.cur * P;
+    const uint8_t *m = mu + (size_t)jb.model * P;
+    const uint8_t *sg = sigma6 + (size_t)jb.model * P;
+    const uint32_t nloop = COMPACT ? (npend + 63u) & ~63u : npend;
+#pragma unroll 1
+    for (uint32_t e = lane; e < nloop; e += 64) {
+        uint32_t Ov[4] = {0, 0, 0, 0};
+        uint32_t pix0 = 0;
+        if (e < npend) {
+            const uint32_t code = pend[e];
+            const int y = (int)(code / ngroups), x0 = (int)(code % ngroups) * 4;
+            int xs[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++)
+                xs[j] = reflect101(x0 - 1 + j, W);
+            int S[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const size_t ro = (size_t)reflect101(y - 1 + i, H) * W;
+                int o[6];
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    int a = (int)f[ro + xs[j]] - (int)m[ro + xs[j]];
+                    a = a < 0 ? -a : a;
+                    a -= (int)sg[ro + xs[j]];
+                    o[j] = a < 0 ? 0 : a;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    S[q] += o[q] + o[q + 1] + o[q + 2];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t v = (uint32_t)(S[q] + 4) / 9u;
+                Ov[q] = v;
+                if (v)
+                    atomicAdd(&hist[(size_t)jb.out * 256 + v], 1u);
+            }
+            if (STORE)
+                *reinterpret_cast<uint32_t *>(img + (size_t)jb.out * P + (size_t)y * W + x0) =
+                    Ov[0] | (Ov[1] << 8) | (Ov[2] << 16) | (Ov[3] << 24);
+            pix0 = (uint32_t)(y * W + x0);
+        }
+        if (COMPACT) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                c += (int)Ov[q] > cp.thr;
+            uint32_t pos = compact_reserve(cp, c);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                compact_put(cp, pos, Ov[q], pix0 + q);
+        }
+    }
+}
+
+template <int NDW, int KF, bool STORE, bool COMPACT>
+__global__ __launch_bounds__(64) void k3_bound_scan(const uint8_t *__restrict__ frames, const uint8_t *__restrict__ mu,
+                                                    const uint8_t *__restrict__ sigma6,
+                                                    const abub_job *__restrict__ jobs, int njobs, int W, int H,
+                                                    int rows_per_chunk, int nchunks, uint32_t *__restrict__ hist,
+                                                    uint8_t *__restrict__ img, uint2 *__restrict__ pieces,
+                                                    uint32_t *__restrict__ npieces, const int32_t *__restrict__ cthr,
+                                                    uint32_t *pairs, uint32_t pcap, uint32_t *pcount, uint32_t slot_base)
+{
+    constexpr int NP = 2 * NDW;
+    constexpr int NG = K3ScanJob<NDW>::NG, GS = K3ScanJob<NDW>::GS;
+    __shared__ uint32_t pend[KF][K3S_PEND];
+    const int lane = threadIdx.x;
+    const int unit = blockIdx.x;
+    const int grp = unit / nchunks;
+    const int chunk = unit - grp * nchunks;
+    const int j0 = grp * KF;
+    const int k = njobs - j0 < KF ? njobs - j0 : KF; // jobs of this wave (>= 1)
+    abub_job jb[KF];
+#pragma unroll
+    for (int t = 0; t < KF; t++)
+        jb[t] = jobs[j0 + (t < k ? t : k - 1)];
     const int y0 = chunk * rows_per_chunk;
     int y1 = y0 + rows_per_chunk;
     if (y1 > H)
         y1 = H;
-    const int T = y1 - y0 + 2; // input rows y0-1 .. y1 (reflected)
-
-    lh[lane] = 0;
-    lh[lane + 64] = 0;
-    lh[lane + 128] = 0;
-    lh[lane + 192] = 0;
-    __syncthreads();
-
-    uint32_t a0[NP], xp[NP];
+    bool shared = true;
 #pragma unroll
-    for (int j = 0; j < NP; j++)
-        a0[j] = xp[j] = 0;
-    uint8_t *obase = STORE ? img + (size_t)jb.out * P + xoff : nullptr;
-    Compact cp;
-    cp.pairs = cthr ? pairs : nullptr;
-    cp.count = pcount;
-    cp.cap = pcap;
-    cp.slot = jb.out + slot_base;
-    cp.thr = cthr ? cthr[jb.out] : 255;
+    for (int t = 1; t < KF; t++)
+        if (t < k && jb[t].model != jb[0].model)
+            shared = false;
+    if (!shared) { // jobs of different cameras in one group: their chunks go to the row machine whole
+#pragma unroll
+        for (int t = 0; t < KF; t++)
+            if (t < k)
+                k2b_hand_over(pieces, npieces, (uint32_t)(j0 + t), y0, y1, lane);
+        return;
+    }
+    const size_t P = (size_t)W * H;
+    const int nl = W / (4 * NDW);
+    const bool active = lane < nl;
+    const bool first_lane = lane == 0, last_lane = lane == nl - 1;
+    const int xoff = active ? lane * 4 * NDW : 0;
+    const uint8_t *m = mu + (size_t)jb[0].model * P;
+    const uint8_t *sg = sigma6 + (size_t)jb[0].model * P;
+    const uint8_t *f[KF];
+    uint8_t *obase[KF];
+    K3ScanJob<NDW> J[KF];
+#pragma unroll
+    for (int t = 0; t < KF; t++) {
+        f[t] = frames + (size_t)jb[t].cur * P;
+        obase[t] = STORE ? img + (size_t)jb[t].out * P + xoff : nullptr;
+#pragma unroll
+        for (int g = 0; g < NG; g++)
+            J[t].Mh[0][g] = J[t].Mh[1][g] = 0;
+        J[t].npend = J[t].hot = 0;
+        J[t].handover = t < k ? -1 : 0x7fffffff;
+    }
+    const int T = y1 - y0 + 2; // input rows r = y0-1 .. y1 (reflected at the image border)
+    const uint32_t ngroups = (uint32_t)W / 4;
 
-    Row3In<NDW> ring[2];
-    k3_load_row<NDW>(ring[0], f, m, sg, reflect101(y0 - 1, H), W, xoff);
-    int zrun = 2; // the vertical state starts out all zero
-    for (int t = 0; t < T; t += 2) {
+    uint32_t raw[2][KF + 2][NDW]; // [KF] = mu, [KF + 1] = sigma6
+#define K3S_LOAD(SL, Y)                                                                         \
+    {                                                                                           \
+        const size_t o_ = (size_t)(Y) * W + xoff;                                               \
+        _Pragma("unroll") for (int t = 0; t < KF; t++)                                          \
+        {                                                                                       \
+            const uint32_t *pf_ = reinterpret_cast<const uint32_t *>(f[t] + o_);                \
+            _Pragma("unroll") for (int d = 0; d < NDW; d++) raw[SL][t][d] = pf_[d];             \
+        }                                                                                       \
+        const uint32_t *pm_ = reinterpret_cast<const uint32_t *>(m + o_);                       \
+        const uint32_t *ps_ = reinterpret_cast<const uint32_t *>(sg + o_);                      \
+        _Pragma("unroll") for (int d = 0; d < NDW; d++)                                         \
+        {                                                                                       \
+            raw[SL][KF][d] = pm_[d];                                                            \
+            raw[SL][KF + 1][d] = ps_[d];                                                        \
+        }                                                                                       \
+    }
+    K3S_LOAD(0, reflect101(y0 - 1, H));
+    const int Tpad = (T + 1) & ~1;
+    for (int t0 = 0; t0 < Tpad; t0 += 2) {
+        bool all_done = true;
+#pragma unroll
+        for (int t = 0; t < KF; t++)
+            all_done = all_done && J[t].handover >= 0;
+        if (all_done)
+            break;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            const int tt = t + u;
-            if (tt < T) {
-                int tn = tt + 1 < T ? tt + 1 : T - 1;
-                k3_load_row<NDW>(ring[(u + 1) & 1], f, m, sg, reflect101(y0 - 1 + tn, H), W, xoff);
-                int y = y0 + tt - 2;
-                k3_row<NDW, STORE>(ring[u], a0, xp, tt >= 2, active, first_lane, last_lane, lh,
-                                   reinterpret_cast<uint32_t *>(obase + (ptrdiff_t)y * W), cp,
-                                   (uint32_t)(y * W + xoff), zrun);
+            const int tt = t0 + u; // input row r = y0 - 1 + tt; completes the bound of output row y = y0 + tt - 2
+            const int tn = tt + 1 < T ? tt + 1 : T - 1;
+            K3S_LOAD(u ^ 1, reflect101(y0 - 1 + tn, H));
+            uint32_t HI[NP], LO[NP];
+            k3_thresholds<NDW>(raw[u][KF], raw[u][KF + 1], HI, LO);
+            const int y = y0 + tt - 2;
+            const bool emit = tt >= 2 && tt < T;
+#pragma unroll
+            for (int t = 0; t < KF; t++) {
+                if (J[t].handover >= 0)
+                    continue;
+                // group masses of O in this input row (u16 halves: <= 2 * 255 each)
+                uint32_t mg[NDW];
+#pragma unroll
+                for (int d = 0; d < NDW; d++) {
+                    const uint32_t f0 = widen_lo(raw[u][t][d]), f1 = widen_hi(raw[u][t][d]);
+                    mg[d] = (pk_subsat(f0, HI[2 * d]) | pk_subsat(LO[2 * d], f0)) +
+                            (pk_subsat(f1, HI[2 * d + 1]) | pk_subsat(LO[2 * d + 1], f1));
+                }
+                uint32_t mL = __builtin_amdgcn_update_dpp(0u, mg[NDW - 1], DPP_WAVE_SHR1, 0xf, 0xf, false);
+                uint32_t mR = __builtin_amdgcn_update_dpp(0u, mg[0], DPP_WAVE_SHL1, 0xf, 0xf, false);
+                mL = first_lane ? mg[0] : mL;
+                mR = last_lane ? mg[NDW - 1] : mR;
+                uint32_t B[NG];
+                uint32_t worst = 0;
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    const int g0 = GS * g, g1 = GS * g + GS - 1 < NDW ? GS * g + GS - 1 : NDW - 1;
+                    uint32_t own = mg[g0];
+#pragma unroll
+                    for (int q = g0 + 1; q <= g1; q++)
+                        own += mg[q];
+                    const uint32_t M = (g0 ? mg[g0 - 1] : mL) + own + (g1 + 1 < NDW ? mg[g1 + 1] : mR);
+                    B[g] = M + J[t].Mh[u ^ 1][g] + J[t].Mh[u][g]; // rows r, r-1, r-2 (Mh[u] still holds row r-2)
+                    J[t].Mh[u][g] = M;
+                    worst |= B[g];
+                }
+                const bool unsure = active && ((worst & 0xffffu) + (worst >> 16)) >= 5u; // (OR over-estimates: verified below)
+                if (emit && __builtin_amdgcn_ballot_w64(unsure)) {
+                    // ---- rare: some group of this output row cannot be proven zero ------------------------
+                    unsigned long long bm[NG];
+                    bool mine[NG];
+                    uint32_t total = 0;
+#pragma unroll
+                    for (int g = 0; g < NG; g++) {
+                        mine[g] = active && ((B[g] & 0xffffu) + (B[g] >> 16)) >= 5u;
+                        bm[g] = __builtin_amdgcn_ballot_w64(mine[g]);
+                        const int nq = GS * g + GS <= NDW ? GS : NDW - GS * g;
+                        total += (uint32_t)nq * (uint32_t)__builtin_popcountll(bm[g]);
+                    }
+                    J[t].hot += total > 32u;
+                    if (J[t].hot >= 4u || J[t].npend + total > K3S_PEND) {
+                        J[t].handover = y;
+                    } else {
+                        const uint32_t code0 = (uint32_t)y * ngroups + (uint32_t)lane * NDW;
+                        uint32_t base = J[t].npend;
+#pragma unroll
+                        for (int g = 0; g < NG; g++) {
+                            const unsigned long long b = bm[g];
+                            if (b) {
+                                const int nq = GS * g + GS <= NDW ? GS : NDW - GS * g;
+                                const uint32_t below =
+                                    __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                                if (mine[g]) {
+#pragma unroll
+                                    for (int q = 0; q < nq; q++)
+                                        pend[t][base + (uint32_t)nq * below + q] = code0 + GS * g + q;
+                                }
+                                base += (uint32_t)nq * (uint32_t)__builtin_popcountll(b);
+                            }
+                        }
+                        J[t].npend = base;
+                    }
+                }
+                if (STORE && emit && J[t].handover < 0 && active) {
+                    // the scan is responsible for this row: zeros now, the tail overwrites its suspect groups
+                    uint32_t *po = reinterpret_cast<uint32_t *>(obase[t] + (ptrdiff_t)y * W);
+#pragma unroll
+                    for (int d = 0; d < NDW; d++)
+                        po[d] = 0;
+                }
             }
         }
     }
-    __syncthreads();
-    uint32_t *gh = hist + (size_t)jb.out * 256;
+#undef K3S_LOAD
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint32_t v = lh[lane + 64 * k];
-        if (v && (lane + 64 * k))
-            atomicAdd(&gh[lane + 64 * k], v);
+    for (int t = 0; t < KF; t++) {
+        if (t < k) {
+            if (J[t].handover >= 0)
+                k2b_hand_over(pieces, npieces, (uint32_t)(j0 + t), J[t].handover, y1, lane);
+            Compact cp;
+            cp.pairs = COMPACT ? pairs : nullptr;
+            cp.count = pcount;
+            cp.cap = pcap;
+            cp.slot = jb[t].out + slot_base;
+            cp.thr = COMPACT ? cthr[jb[t].out] : 255;
+            k3s_tail<COMPACT, STORE>(pend[t], J[t].npend, jb[t], frames, mu, sigma6, W, H, hist, img, cp, lane);
+        }
     }
 }
 
-template <int NDW>
-static void launch_k3_rows(const uint8_t *frames, const uint8_t *mu, const uint8_t *sigma6, const abub_job *jobs,
-                           int njobs, int W, int H, int R, int nchunks, uint32_t *hist, uint8_t *img,
-                           const CompactArgs &ca, hipStream_t st)
+static int k3_scan_enabled()
 {
-    dim3 grid((unsigned)njobs * nchunks), block(64);
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("ABUB_K3_SCAN"); // 0: the row machine on every row (no zero scan)
+        on = e ? atoi(e) : 1;
+    }
+    return on;
+}
+
+template <int NDW>
+static int launch_k3_rows(const uint8_t *frames, const uint8_t *mu, const uint8_t *sigma6, const abub_job *jobs,
+                          int njobs, int W, int H, int R, int nchunks, uint32_t *hist, uint8_t *img,
+                          const CompactArgs &ca, hipStream_t st)
+{
+#define K3R_LAUNCH(ST, GRID, PL, PC)                                                                                 \
+    hipLaunchKernelGGL((k3_rows<NDW, ST>), dim3(GRID), dim3(64), 0, st, frames, mu, sigma6, jobs, W, H, R, nchunks,   \
+                       hist, img, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base, PL, PC)
+    if (k3_scan_enabled() && H < 65536 && (size_t)H * (size_t)(W / 4) < ((size_t)1 << 32)) {
+        constexpr int KF = NDW <= 5 ? 5 : (NDW <= 7 ? 4 : 3); // jobs per scanning wave (register budget)
+        const size_t nunits = (size_t)njobs * nchunks;
+        const size_t cap = nunits * (size_t)((R + K2B_SUB - 1) / K2B_SUB); // handed-over pieces, worst case
+        std::unique_lock<std::mutex> hold;
+        uint8_t *scr = (uint8_t *)k2_scratch(st, 256 + cap * sizeof(uint2) + 256, hold);
+        if (!scr)
+            return set_err(ABUB_E_HIP, "abub_posttrig_dev: scratch allocation failed");
+        uint32_t *counter = (uint32_t *)scr;
+        uint2 *pieces = (uint2 *)(scr + 256);
+        HIPCHK(hipMemsetAsync(counter, 0, sizeof(uint32_t), st));
+        const dim3 sgrid((unsigned)((size_t)((njobs + KF - 1) / KF) * nchunks));
+#define K3S_LAUNCH(ST, CO)                                                                                          \
+    hipLaunchKernelGGL((k3_bound_scan<NDW, KF, ST, CO>), sgrid, dim3(64), 0, st, frames, mu, sigma6, jobs, njobs, W, \
+                       H, R, nchunks, hist, img, pieces, counter, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base)
+        if (ca.cthr) {
+            if (img)
+                K3S_LAUNCH(true, true);
+            else
+                K3S_LAUNCH(false, true);
+        } else {
+            if (img)
+                K3S_LAUNCH(true, false);
+            else
+                K3S_LAUNCH(false, false);
+        }
+#undef K3S_LAUNCH
+        const unsigned g = (unsigned)(cap < 8192 ? cap : 8192);
+        if (img)
+            K3R_LAUNCH(true, g, pieces, counter);
+        else
+            K3R_LAUNCH(false, g, pieces, counter);
+        return ABUB_OK;
+    }
+    const unsigned grid = (unsigned)njobs * nchunks;
     if (img)
-        hipLaunchKernelGGL((k3_rows<NDW, true>), grid, block, 0, st, frames, mu, sigma6, jobs, W, H, R, nchunks,
-                           hist, img, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base);
+        K3R_LAUNCH(true, grid, (const uint2 *)nullptr, (const uint32_t *)nullptr);
     else
-        hipLaunchKernelGGL((k3_rows<NDW, false>), grid, block, 0, st, frames, mu, sigma6, jobs, W, H, R, nchunks,
-                           hist, img, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base);
+        K3R_LAUNCH(false, grid, (const uint2 *)nullptr, (const uint32_t *)nullptr);
+#undef K3R_LAUNCH
+    return ABUB_OK;
 }
 
 static int posttrig_impl(const uint8_t *frames, const uint8_t *mu, const uint8_t *sigma6, const abub_job *jobs,
@@ -1926,16 +2279,19 @@ static int posttrig_impl(const uint8_t *frames, const uint8_t *mu, const uint8_t
         if (R < 16)
             R = 16;
         int nchunks = (H + R - 1) / R;
+        int rc3 = ABUB_OK;
         switch (ndw) {
-        case 1: launch_k3_rows<1>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
-        case 2: launch_k3_rows<2>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
-        case 3: launch_k3_rows<3>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
-        case 4: launch_k3_rows<4>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
-        case 5: launch_k3_rows<5>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
-        case 6: launch_k3_rows<6>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
-        case 7: launch_k3_rows<7>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
-        default: launch_k3_rows<8>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
+        case 1: rc3 = launch_k3_rows<1>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
+        case 2: rc3 = launch_k3_rows<2>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
+        case 3: rc3 = launch_k3_rows<3>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
+        case 4: rc3 = launch_k3_rows<4>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
+        case 5: rc3 = launch_k3_rows<5>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
+        case 6: rc3 = launch_k3_rows<6>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
+        case 7: rc3 = launch_k3_rows<7>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
+        default: rc3 = launch_k3_rows<8>(frames, mu, sigma6, jobs, njobs, W, H, R, nchunks, hist, img, ca, st); break;
         }
+        if (rc3 != ABUB_OK)
+            return rc3;
     } else {
         if (ca.cthr)
             return set_err(ABUB_E_INVALID, "fused compaction needs the fast path (W % 4 == 0, W <= 2048)");

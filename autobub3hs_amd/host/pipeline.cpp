@@ -756,13 +756,16 @@ private:
         // other down -- while the host stages of group g run under the kernels of group g+1.
         hipStream_t stream = ordered ? stage1Stream : G.stream;
         hipStream_t back = G.stream;
-        // slots: all genesis images first (K2), then all post-trigger images (K3)
+        // slots: all genesis images first (K2), then all post-trigger images (K3), camera-major: consecutive K3 jobs
+        // then share their model, which is what lets one scanning wave serve several tracking frames (k3_zero_scan)
         int nd = 0, np = 0;
         for (int s : loc)
             for (PlannedImage &p : stacks[s].data.planned)
                 (p.kind == 0 ? nd : np)++;
+        std::vector<int> order(loc);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return a % C < b % C; });
         int di = 0, pi = nd;
-        for (int s : loc) {
+        for (int s : order) {
             const int c = s % C;
             for (PlannedImage &p : stacks[s].data.planned) {
                 p.slot = p.kind == 0 ? di++ : pi++;
