@@ -61,22 +61,34 @@ extern "C" int abub_ctx_create(abub_ctx **out, int device, int W, int H, int max
     c->maxF = max_frames;
     c->P = (size_t)W * H;
     c->idx_cap = 1 << 16;
-    CCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CCHK(hipMalloc((void **)&c->d_frames, c->P * max_frames));
-    CCHK(hipMalloc((void **)&c->d_mu, c->P));
-    CCHK(hipMalloc((void **)&c->d_sigma, c->P));
-    CCHK(hipMalloc((void **)&c->d_sigma6, c->P));
-    CCHK(hipMalloc((void **)&c->d_img, c->P));
-    CCHK(hipMalloc((void **)&c->d_hist, (size_t)max_frames * 256 * sizeof(uint32_t)));
-    CCHK(hipMalloc((void **)&c->d_jobs, (size_t)max_frames * sizeof(abub_job)));
-    CCHK(hipMalloc((void **)&c->d_idx, (size_t)c->idx_cap * sizeof(uint32_t)));
-    CCHK(hipMalloc((void **)&c->d_count, sizeof(uint32_t)));
-    CCHK(hipMalloc((void **)&c->d_thr, sizeof(int32_t)));
-    CCHK(hipHostMalloc((void **)&c->h_stage, c->P * max_frames, hipHostMallocDefault));
-    CCHK(hipHostMalloc((void **)&c->h_hist, (size_t)max_frames * 256 * sizeof(uint32_t), hipHostMallocDefault));
-    CCHK(hipHostMalloc((void **)&c->h_job, sizeof(abub_job), hipHostMallocDefault));
-    CCHK(hipHostMalloc((void **)&c->h_small, 4 * sizeof(uint32_t), hipHostMallocDefault));
-    CCHK(hipHostMalloc((void **)&c->h_idx, (size_t)c->idx_cap * sizeof(uint32_t), hipHostMallocDefault));
+    *out = nullptr;
+    // any failure below gives the partly built context back (destroy tolerates null members)
+#define CTRY(x)                                           \
+    do {                                                  \
+        hipError_t e_ = (x);                              \
+        if (e_ != hipSuccess) {                           \
+            const int rc_ = cfail(ABUB_E_HIP, #x, e_);    \
+            abub_ctx_destroy(c);                          \
+            return rc_;                                   \
+        }                                                 \
+    } while (0)
+    CTRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CTRY(hipMalloc((void **)&c->d_frames, c->P * max_frames));
+    CTRY(hipMalloc((void **)&c->d_mu, c->P));
+    CTRY(hipMalloc((void **)&c->d_sigma, c->P));
+    CTRY(hipMalloc((void **)&c->d_sigma6, c->P));
+    CTRY(hipMalloc((void **)&c->d_img, c->P));
+    CTRY(hipMalloc((void **)&c->d_hist, (size_t)max_frames * 256 * sizeof(uint32_t)));
+    CTRY(hipMalloc((void **)&c->d_jobs, (size_t)max_frames * sizeof(abub_job)));
+    CTRY(hipMalloc((void **)&c->d_idx, (size_t)c->idx_cap * sizeof(uint32_t)));
+    CTRY(hipMalloc((void **)&c->d_count, sizeof(uint32_t)));
+    CTRY(hipMalloc((void **)&c->d_thr, sizeof(int32_t)));
+    CTRY(hipHostMalloc((void **)&c->h_stage, c->P * max_frames, hipHostMallocDefault));
+    CTRY(hipHostMalloc((void **)&c->h_hist, (size_t)max_frames * 256 * sizeof(uint32_t), hipHostMallocDefault));
+    CTRY(hipHostMalloc((void **)&c->h_job, sizeof(abub_job), hipHostMallocDefault));
+    CTRY(hipHostMalloc((void **)&c->h_small, 4 * sizeof(uint32_t), hipHostMallocDefault));
+    CTRY(hipHostMalloc((void **)&c->h_idx, (size_t)c->idx_cap * sizeof(uint32_t), hipHostMallocDefault));
+#undef CTRY
     *out = c;
     return ABUB_OK;
 }
@@ -86,7 +98,8 @@ extern "C" void abub_ctx_destroy(abub_ctx *c)
     if (!c)
         return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream)
+        (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_frames);
     (void)hipFree(c->d_mu);
     (void)hipFree(c->d_sigma);
@@ -102,8 +115,10 @@ extern "C" void abub_ctx_destroy(abub_ctx *c)
     (void)hipHostFree(c->h_job);
     (void)hipHostFree(c->h_small);
     (void)hipHostFree(c->h_idx);
-    (void)abub_scratch_release(c->stream);
-    (void)hipStreamDestroy(c->stream);
+    if (c->stream) {
+        (void)abub_scratch_release(c->stream);
+        (void)hipStreamDestroy(c->stream);
+    }
     free(c);
 }
 
@@ -320,19 +335,24 @@ extern "C" int abub_ctx_match_template(abub_ctx *c, int i, const uint8_t *tmpl, 
     const size_t n = (size_t)(c->W - tw + 1) * (c->H - th + 1);
     uint8_t *d_t = nullptr;
     unsigned long long *d_num = nullptr, *d_w = nullptr;
-    CCHK(hipMalloc((void **)&d_t, (size_t)tw * th));
-    CCHK(hipMalloc((void **)&d_num, n * 8));
-    CCHK(hipMalloc((void **)&d_w, n * 8));
+    // (the temporaries are freed on every exit path: a failed allocation must not leak the earlier ones)
+    hipError_t e = hipMalloc((void **)&d_t, (size_t)tw * th);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&d_num, n * 8);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&d_w, n * 8);
     int rc = ABUB_OK;
-    hipError_t e = hipMemcpyAsync(d_t, tmpl, (size_t)tw * th, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_t, tmpl, (size_t)tw * th, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess)
         rc = abub_match_ccorr_dev(c->d_frames + (size_t)i * c->P, c->W, c->H, d_t, tw, th, d_num, d_w, c->stream);
     if (e == hipSuccess && rc == ABUB_OK)
         e = hipMemcpyAsync(num_out, d_num, n * 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess && rc == ABUB_OK)
         e = hipMemcpyAsync(wsum2_out, d_w, n * 8, hipMemcpyDeviceToHost, c->stream);
+    const hipError_t es = hipStreamSynchronize(c->stream); // also before freeing buffers a queued kernel may use
     if (e == hipSuccess)
-        e = hipStreamSynchronize(c->stream);
+        e = es;
     (void)hipFree(d_t);
     (void)hipFree(d_num);
     (void)hipFree(d_w);

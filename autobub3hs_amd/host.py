@@ -205,6 +205,14 @@ def imdecode(data, cap=1 << 22):
     return out[: w.value * h.value].reshape(h.value, w.value).copy()
 
 
+def imwrite(path, img):
+    """cvlite's cv::imwrite (debug image write-out): 8-bit grey PNG, or BMP when the name ends in .bmp."""
+    L = lib()
+    L.abh_imwrite.argtypes = [C.c_char_p, _u8p, C.c_int, C.c_int]
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    return L.abh_imwrite(path.encode(), img.ctypes.data_as(_u8p), img.shape[1], img.shape[0]) == 0
+
+
 def write_header(outdir, run_number, frame_offset, ncams):
     """OutputWriter::writeHeader -> <outdir>abub3hs_<run>.txt (outdir is used as a prefix, like upstream)."""
     lib().abh_write_header(outdir.encode(), run_number.encode(), frame_offset, ncams)

@@ -6,7 +6,9 @@
 #include "AnalyzerUnit.hpp"
 
 #include <cassert>
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <iostream>
 #include <stdexcept>
@@ -83,7 +85,7 @@ void AnalyzerUnit::ProcessFrame(cv::Mat &workingFrame, cv::Mat &prevFrame, cv::M
     abub::DeviceContext &dc = abub::DeviceContext::forThread(workingFrame.cols, workingFrame.rows, 2);
     const uint8_t *fr[2] = {workingFrame.data, prevFrame.data};
     abub::check(abub_ctx_upload_stack(dc.ctx, fr, 2), "abub_ctx_upload_stack");
-    dc.residentEvent = nullptr;
+    dc.residentEvent = 0;
     dc.ensureModel(*TrainedData);
     diff_frame.create(workingFrame.rows, workingFrame.cols, CV_8U);
     const bool full = ROI.x == 0 && ROI.y == 0 && ROI.width == workingFrame.cols && ROI.height == workingFrame.rows;
@@ -101,7 +103,7 @@ float AnalyzerUnit::calculateEntropyFrame(cv::Mat &img, bool)
     std::vector<uint8_t> zeros(img.total(), 0);
     uint32_t h[256];
     abub::check(abub_ctx_pair_hist(dc.ctx, zeros.data(), img.data, h), "abub_ctx_pair_hist");
-    dc.residentEvent = nullptr;
+    dc.residentEvent = 0;
     return abub::entropyFromHist(h, 128, img.total());
 }
 
@@ -121,8 +123,43 @@ double AnalyzerUnit::calculateSignificanceFrame(cv::Mat &img, bool store, bool)
     std::vector<uint8_t> zeros(img.total(), 0);
     uint32_t h[256];
     abub::check(abub_ctx_pair_hist(dc.ctx, zeros.data(), img.data, h), "abub_ctx_pair_hist");
-    dc.residentEvent = nullptr;
+    dc.residentEvent = 0;
     return abub::significanceFromHist(pix_counts, h, img.total(), store, TrainedData->TrainingSetSize, loc_thres_max, loc_thres);
+}
+
+// ---- debug image write-out of the trigger search (AnalyzerUnit.cpp:233-238, 353-365): only with the analyzer debug
+// digit (nonStopMode == false), into $HOME/test/abub_debug/ which must exist.  The pos / neg planes and their
+// filtered versions are intermediate images of the fused kernel that never exist on the GPU; for the dump they are
+// formed on the host from the decoded frames (reference formulas; results of the analysis never come from here).
+static void debugPlanes(const cv::Mat &cur, const cv::Mat &ref, const cv::Mat &sigma, cv::Mat out[4])
+{
+    const int W = cur.cols, H = cur.rows;
+    for (int k = 0; k < 4; ++k)
+        out[k].create(H, W, CV_8U);
+    for (size_t i = 0; i < (size_t)W * H; ++i) {
+        const int c = cur.data[i], r = ref.data[i], s6 = 6 * (int)sigma.data[i];
+        out[0].data[i] = (uchar)std::max(0, c - r - s6); // pos_diff (:351)
+        out[1].data[i] = (uchar)std::max(0, r - c - s6); // neg_diff (:352)
+    }
+    auto refl = [](int p, int n) { return n == 1 ? 0 : (p < 0 ? -p : (p >= n ? 2 * n - 2 - p : p)); };
+    static const int wt[5] = {1, 4, 6, 4, 1};
+    std::vector<int> tmp((size_t)W * H);
+    for (int k = 0; k < 2; ++k) { // cv::GaussianBlur 5x5, sigma 0, BORDER_REFLECT_101: (S + 128) >> 8 (:359-360)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                int acc = 0;
+                for (int j = -2; j <= 2; ++j)
+                    acc += wt[j + 2] * out[k].data[(size_t)y * W + refl(refl(x + j, W), W)];
+                tmp[(size_t)y * W + x] = acc;
+            }
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                int acc = 0;
+                for (int j = -2; j <= 2; ++j)
+                    acc += wt[j + 2] * tmp[(size_t)refl(refl(y + j, H), H) * W + x];
+                out[2 + k].data[(size_t)y * W + x] = (uchar)((acc + 128) >> 8);
+            }
+    }
 }
 
 void AnalyzerUnit::FindTriggerFrame(bool nonStopMode, int startframe)
@@ -160,6 +197,29 @@ void AnalyzerUnit::FindTriggerFrame(bool nonStopMode, int startframe)
                                           TrainedData->TrainingSetSize, loc_thres_max, loc_thres);
     };
 
+    const int frame_num_offset = 50 - (n - 1) / 2; // (:130, used by the debug prints only)
+    const char *home = getenv("HOME");
+    const std::string dbgDir = std::string(home ? home : ".") + "/test/abub_debug/ev_" + EventID + "_";
+    auto debugDump = [&](int frame, double sig, bool print) {
+        if (print)
+            std::cout << "Entropy of BkgSub " << frame + frame_num_offset << " image: " << (float)sig << "\n";
+        const int ref = std::max(frame - refOffset, 0);
+        cv::Mat cur = ev.hostFrame(frame), prv = ev.hostFrame(ref);
+        if (!cur.empty() && !prv.empty()) {
+            cv::Mat pl[4];
+            debugPlanes(cur, prv, TrainedData->TrainedSigmaImage, pl);
+            cv::imwrite(dbgDir + "pos_" + CameraFrames[frame], pl[0]);
+            cv::imwrite(dbgDir + "neg_" + CameraFrames[frame], pl[1]);
+            cv::imwrite(dbgDir + "pos_filter_" + CameraFrames[frame], pl[2]);
+            cv::imwrite(dbgDir + "neg_filter_" + CameraFrames[frame], pl[3]);
+        }
+        if (print) {
+            cv::Mat D;
+            ev.diffFrame(frame, ref, &D);
+            cv::imwrite(dbgDir + CameraFrames[frame], D);
+        }
+    };
+
     for (int i = startframe; i < n; i++) {
         if (!ev.frameOk(i)) { // Parser::GetImage == -1 on the frame under evaluation
             std::cout << "Image " << CameraFrames[i] << " is corrupted/empty of camera " << CameraNumber << " for the event " << EventID << "." << std::endl;
@@ -168,6 +228,8 @@ void AnalyzerUnit::FindTriggerFrame(bool nonStopMode, int startframe)
             return;
         }
         float singleEntropy = (float)significance(i, true);
+        if (!nonStopMode)
+            debugDump(i, singleEntropy, true);
         if (singleEntropy > entropyThreshold && i >= minEvalFrameNumber) {
             // LED-flicker veto: the next two frames must stay significant
             if (i != n - 1) {
@@ -177,6 +239,8 @@ void AnalyzerUnit::FindTriggerFrame(bool nonStopMode, int startframe)
                     if (!ev.frameOk(i + ii))
                         throw std::runtime_error("AnalyzerUnit::FindTriggerFrame: undecodable look-ahead frame");
                     singleEntropy = (float)significance(i + ii, false);
+                    if (!nonStopMode)
+                        debugDump(i + ii, singleEntropy, false); // (the look-ahead only dumps the planes, :286)
                     if (singleEntropy / (entropyThreshold / 3.5 * 5) + singleEntropy / max_so_far <= 3)
                         break;
                     else if (ii == numFramesCheck) {

@@ -13,6 +13,6 @@ float calculateEntropyFrame(cv::Mat &ImageFrame)
     std::vector<uint8_t> zeros(ImageFrame.total(), 0);
     uint32_t h[256];
     abub::check(abub_ctx_pair_hist(dc.ctx, zeros.data(), ImageFrame.data, h), "abub_ctx_pair_hist");
-    dc.residentEvent = nullptr;
+    dc.residentEvent = 0;
     return abub::entropyFromHist(h, 16, ImageFrame.total());
 }

@@ -47,11 +47,16 @@ static cv::Mat cachedMask(const std::string &path);
 static thread_local abub::ContourFinder t_finder;
 
 static void contoursOfCurrentImage(abub::EventData &ev, const uint32_t *hist, int tozeroThr,
-                                   std::vector<std::vector<cv::Point>> &contours)
+                                   std::vector<std::vector<cv::Point>> &contours, cv::Mat *debugMask = nullptr)
 {
     const int thr = abub::binarizeThresholdFromHist(hist, (size_t)ev.W * ev.H, tozeroThr);
     std::vector<uint32_t> fg;
     ev.foreground(thr, fg);
+    if (debugMask) { // the thresholded image of L3Localizer.cpp:254 (debug write-out only)
+        *debugMask = cv::Mat::zeros(ev.H, ev.W, CV_8U);
+        for (uint32_t i : fg)
+            debugMask->data[i] = 255;
+    }
     t_finder.find(fg, ev.W, ev.H, contours);
 }
 
@@ -96,9 +101,26 @@ void L3Localizer::CalculateInitialBubbleParams(void)
     int pre = MatTrigFrame - prevOffset;
     if (pre < 0)
         pre = 0;
-    const uint32_t *hist = ev.diffFrame(MatTrigFrame, pre);
+    // debug write-out (L3Localizer.cpp:222-257, 448-449): only with the localizer debug digit; DebugPeek/ must exist
+    const bool dbg = !nonStopMode;
+    const int frame_num_offset = 50 - ((int)CameraFrames.size() - 1) / 2;
+    const std::string peek = "DebugPeek/ev" + EventID + "_cam" + std::to_string(CameraNumber);
+    cv::Mat overTheSigma, thresFrame;
+    if (dbg)
+        std::cout << "-----Start ev " << EventID << ", cam " << CameraNumber << ", frame " << MatTrigFrame + frame_num_offset
+                  << "-----" << std::endl;
+    const uint32_t *hist = ev.diffFrame(MatTrigFrame, pre, dbg ? &overTheSigma : nullptr);
+    if (dbg) {
+        cv::imwrite(peek + "_000_AvgImage.png", TrainedData->TrainedAvgImage);
+        cv::imwrite(peek + "_00_PreTrigFrame.png", preTrigFrame);
+        cv::imwrite(peek + "_0_TrigFrame.png", triggerFrame);
+        cv::imwrite(peek + "_02_OvrThe6Sigma.png", overTheSigma);
+        std::cout << "this->loc_thres: " << loc_thres << std::endl;
+    }
     std::vector<std::vector<cv::Point>> contours;
-    contoursOfCurrentImage(ev, hist, loc_thres, contours);
+    contoursOfCurrentImage(ev, hist, loc_thres, contours, dbg ? &thresFrame : nullptr);
+    if (dbg)
+        cv::imwrite(peek + "_3_OtsuThresholded.png", thresFrame);
 
     std::vector<cv::Rect> minRect(contours.size());
     int largestBoxArea = 0;
@@ -168,11 +190,18 @@ void L3Localizer::CalculateInitialBubbleParams(void)
         const int BoxArea = minRect[i].width * minRect[i].height;
         if (BoxArea > 10 || BoxArea >= largestBoxArea) {
             bubbleRects.push_back(minRect[i]);
+            if (dbg && !presentationFrame.empty())
+                cv::rectangle(presentationFrame, minRect[i], cv::Scalar(255, 255, 255), 1, 8, 0); // (:397)
             BubbleImageFrame f = describe(contours[i], minRect[i], true);
             if (!isInMask(&f.newPosition))
                 continue; // genesis outside the fiducial mask
             BubbleList.push_back(new bubble(f));
         }
+    }
+    if (dbg) {
+        cv::imwrite(peek + "_4_BubbleDetected.png", presentationFrame);
+        std::cout << "-----End ev " << EventID << ", cam " << CameraNumber << ", frame " << MatTrigFrame + frame_num_offset
+                  << "-----" << std::endl;
     }
 }
 
@@ -311,7 +340,7 @@ void L3Localizer::TrackAFeature(cv::Mat &frame, cv::Mat TemplateImage, cv::Point
     abub::DeviceContext &dc = abub::DeviceContext::forThread(frame.cols, frame.rows, 2);
     const uint8_t *fr[1] = {frame.data};
     abub::check(abub_ctx_upload_stack(dc.ctx, fr, 1), "abub_ctx_upload_stack");
-    dc.residentEvent = nullptr;
+    dc.residentEvent = 0;
     const int rw = frame.cols - TemplateImage.cols + 1, rh = frame.rows - TemplateImage.rows + 1;
     std::vector<unsigned long long> num((size_t)rw * rh), w2((size_t)rw * rh);
     abub::check(abub_ctx_match_template(dc.ctx, 0, TemplateImage.data, TemplateImage.cols, TemplateImage.rows, num.data(),

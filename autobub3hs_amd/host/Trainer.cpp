@@ -70,7 +70,7 @@ float Trainer::calculateEntropyFrame(cv::Mat &img)
     zeros.assign(img.total(), 0);
     uint32_t h[256];
     abub::check(abub_ctx_pair_hist(dc.ctx, zeros.data(), img.data, h), "abub_ctx_pair_hist");
-    dc.residentEvent = nullptr;
+    dc.residentEvent = 0;
     return abub::entropyFromHist(h, 16, img.total());
 }
 
@@ -90,7 +90,7 @@ void Trainer::CalculateMeanSigmaImageVector(std::vector<cv::Mat> &images, cv::Ma
     sigma.create(rows, cols, CV_8U);
     abub::DeviceContext &dc = abub::DeviceContext::forThread(cols, rows, 2);
     abub::check(abub_ctx_train(dc.ctx, ptrs.data(), (int)ptrs.size(), mean.data, sigma.data), "abub_ctx_train");
-    dc.residentEvent = nullptr;
+    dc.residentEvent = 0;
     dc.residentModel = 0; // abub_ctx_train leaves ITS result resident; force a keyed upload on next use
 }
 
@@ -125,7 +125,7 @@ void Trainer::MakeAvgSigmaImage(bool PerformLBPOnImages)
             abub::DeviceContext &dc = abub::DeviceContext::forThread(pair[0].cols, pair[0].rows, 2);
             uint32_t h[256];
             abub::check(abub_ctx_pair_hist(dc.ctx, pair[0].data, pair[1].data, h), "abub_ctx_pair_hist");
-            dc.residentEvent = nullptr;
+            dc.residentEvent = 0;
             entropy = abub::entropyFromHist(h, 16, pair[0].total());
         }
         if (entropy <= 0.0005 && good)

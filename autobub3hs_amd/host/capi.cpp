@@ -181,6 +181,14 @@ int abh_imdecode(const uint8_t *data, int n, uint8_t *out, int cap, int *w, int 
     return 0;
 }
 
+// cv::imwrite of the debug write-out (PNG, or BMP by extension)
+int abh_imwrite(const char *path, const uint8_t *img, int W, int H)
+{
+    cv::Mat m(H, W, CV_8U);
+    std::memcpy(m.data, img, (size_t)W * H);
+    return cv::imwrite(path, m) ? 0 : -1;
+}
+
 void abh_run_free(void *r)
 {
     Run *run = (Run *)r;

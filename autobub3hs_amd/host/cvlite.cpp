@@ -7,6 +7,7 @@
 #include "cvlite.hpp"
 
 #ifndef ABUB_USE_OPENCV
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -207,6 +208,96 @@ Mat imdecode(const uchar *data, size_t size, int)
 }
 
 Mat imdecode(const std::vector<uchar> &buf, int flags) { return imdecode(buf.data(), buf.size(), flags); }
+
+namespace {
+void put32be(std::vector<uchar> &v, uint32_t x)
+{
+    v.push_back((uchar)(x >> 24));
+    v.push_back((uchar)(x >> 16));
+    v.push_back((uchar)(x >> 8));
+    v.push_back((uchar)x);
+}
+void pngChunk(std::vector<uchar> &out, const char *type, const std::vector<uchar> &data)
+{
+    put32be(out, (uint32_t)data.size());
+    const size_t at = out.size();
+    out.insert(out.end(), type, type + 4);
+    out.insert(out.end(), data.begin(), data.end());
+    put32be(out, (uint32_t)crc32(0L, out.data() + at, (uInt)(out.size() - at)));
+}
+} // namespace
+
+bool imwrite(const std::string &path, const Mat &img)
+{
+    if (img.empty())
+        return false;
+    const int W = img.cols, H = img.rows;
+    std::vector<uchar> out;
+    const bool bmp = path.size() >= 4 && (path.compare(path.size() - 4, 4, ".bmp") == 0 || path.compare(path.size() - 4, 4, ".BMP") == 0);
+    if (bmp) {
+        const uint32_t stride = (uint32_t)(W + 3) / 4 * 4, off = 14 + 40 + 1024, size = off + stride * (uint32_t)H;
+        auto le16 = [&](uint32_t x) { out.push_back((uchar)x); out.push_back((uchar)(x >> 8)); };
+        auto le32 = [&](uint32_t x) { le16(x & 0xffff); le16(x >> 16); };
+        out.push_back('B');
+        out.push_back('M');
+        le32(size); le32(0); le32(off);
+        le32(40); le32((uint32_t)W); le32((uint32_t)H); le16(1); le16(8); le32(0); le32(stride * (uint32_t)H); le32(2835); le32(2835);
+        le32(256); le32(0);
+        for (int i = 0; i < 256; ++i) {
+            out.push_back((uchar)i); out.push_back((uchar)i); out.push_back((uchar)i); out.push_back(0);
+        }
+        for (int y = H - 1; y >= 0; --y) {
+            out.insert(out.end(), img.ptr<uchar>(y), img.ptr<uchar>(y) + W);
+            out.insert(out.end(), stride - (uint32_t)W, 0);
+        }
+    } else {
+        static const uchar sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+        out.insert(out.end(), sig, sig + 8);
+        std::vector<uchar> ihdr;
+        put32be(ihdr, (uint32_t)W);
+        put32be(ihdr, (uint32_t)H);
+        const uchar tail[5] = {8, 0, 0, 0, 0}; // 8-bit grey, deflate, adaptive filtering, no interlace
+        ihdr.insert(ihdr.end(), tail, tail + 5);
+        pngChunk(out, "IHDR", ihdr);
+        std::vector<uchar> raw((size_t)(W + 1) * H);
+        for (int y = 0; y < H; ++y) {
+            raw[(size_t)y * (W + 1)] = 0; // filter type None
+            std::memcpy(&raw[(size_t)y * (W + 1) + 1], img.ptr<uchar>(y), (size_t)W);
+        }
+        uLongf clen = compressBound((uLong)raw.size());
+        std::vector<uchar> z(clen);
+        if (compress2(z.data(), &clen, raw.data(), (uLong)raw.size(), 1) != Z_OK)
+            return false;
+        z.resize(clen);
+        pngChunk(out, "IDAT", z);
+        pngChunk(out, "IEND", std::vector<uchar>());
+    }
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f)
+        return false;
+    const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    return fclose(f) == 0 && ok;
+}
+
+void rectangle(Mat &img, const Rect &r, const Scalar &color, int, int, int)
+{
+    if (img.empty() || r.width <= 0 || r.height <= 0)
+        return;
+    const uchar v = (uchar)std::min(255.0, std::max(0.0, color.val[0]));
+    const int x0 = r.x, x1 = r.x + r.width - 1, y0 = r.y, y1 = r.y + r.height - 1;
+    for (int x = std::max(x0, 0); x <= std::min(x1, img.cols - 1); ++x) {
+        if (y0 >= 0 && y0 < img.rows)
+            img.ptr<uchar>(y0)[x] = v;
+        if (y1 >= 0 && y1 < img.rows)
+            img.ptr<uchar>(y1)[x] = v;
+    }
+    for (int y = std::max(y0, 0); y <= std::min(y1, img.rows - 1); ++y) {
+        if (x0 >= 0 && x0 < img.cols)
+            img.ptr<uchar>(y)[x0] = v;
+        if (x1 >= 0 && x1 < img.cols)
+            img.ptr<uchar>(y)[x1] = v;
+    }
+}
 
 Mat imread(const std::string &path, int flags)
 {

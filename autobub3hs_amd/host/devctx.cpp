@@ -1,5 +1,6 @@
 #include "devctx.hpp"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -27,7 +28,19 @@ static int pickDevice()
     return d % n;
 }
 
-static thread_local DeviceContext *t_ctx = nullptr;
+// One context per host thread, owned by a thread_local holder: a worker thread that ends (the CLI's per-camera
+// training threads, its event workers) gives its HBM slab and pinned staging buffers back.
+struct ContextHolder {
+    DeviceContext *p = nullptr;
+    ~ContextHolder() { delete p; }
+};
+static thread_local ContextHolder t_holder;
+#define t_ctx (t_holder.p)
+
+// Resident stacks are identified by a process-wide serial number, not by the address of their EventOnDevice: an
+// event made resident on thread A and destroyed on thread B cannot leave A's context believing that a later object
+// at the same address is already uploaded.
+static std::atomic<unsigned long long> g_eventSerial{1};
 
 DeviceContext::~DeviceContext()
 {
@@ -75,7 +88,7 @@ void DeviceContext::ensureModel(const Trainer &t)
 
 EventOnDevice::EventOnDevice(Parser *parser, const std::string &eventID,
                              const std::vector<std::string> &frameNames, const Trainer *model)
-    : model_(model)
+    : model_(model), serial_(g_eventSerial.fetch_add(1))
 {
     F = (int)frameNames.size();
     frames.resize(F);
@@ -98,8 +111,8 @@ EventOnDevice::EventOnDevice(Parser *parser, const std::string &eventID,
 EventOnDevice::~EventOnDevice()
 {
     // the context must forget a stack whose owner goes away
-    if (t_ctx && t_ctx->residentEvent == this)
-        t_ctx->residentEvent = nullptr;
+    if (t_ctx && t_ctx->residentEvent == serial_)
+        t_ctx->residentEvent = 0; // (a context of another thread may keep the stale serial: it can never match again)
 }
 
 DeviceContext &EventOnDevice::resident()
@@ -107,7 +120,7 @@ DeviceContext &EventOnDevice::resident()
     if (W == 0)
         throw std::runtime_error("abub: event has no decodable frame");
     DeviceContext &dc = DeviceContext::forThread(W, H, F);
-    if (dc.residentEvent != this) {
+    if (dc.residentEvent != serial_) {
         // undecodable frames travel as zeros; the state machines never read their results
         static thread_local std::vector<uint8_t> zeros;
         if (zeros.size() < (size_t)W * H)
@@ -116,7 +129,7 @@ DeviceContext &EventOnDevice::resident()
         for (int i = 0; i < F; ++i)
             ptrs[i] = frames[i].empty() ? zeros.data() : frames[i].data;
         check(abub_ctx_upload_stack(dc.ctx, ptrs.data(), F), "abub_ctx_upload_stack");
-        dc.residentEvent = this;
+        dc.residentEvent = serial_;
     }
     dc.ensureModel(*model_);
     return dc;

@@ -28,7 +28,7 @@ public:
     abub_ctx *ctx = nullptr;
     int W = 0, H = 0, maxF = 0;
     unsigned long long residentModel = 0; // Trainer::ModelId currently in HBM
-    const void *residentEvent = nullptr;  // EventOnDevice currently in the frame slab
+    unsigned long long residentEvent = 0; // serial of the EventOnDevice currently in the frame slab (0: none)
     void ensureModel(const Trainer &t);
     ~DeviceContext();
 };
@@ -88,6 +88,7 @@ public:
 private:
     DeviceContext &resident();
     const Trainer *model_;
+    unsigned long long serial_; // process-wide, never reused (what DeviceContext::residentEvent remembers)
     std::vector<uint32_t> hists_[3]; // per refOffset (1,2): [F][256], empty until computed
     uint32_t lastHist_[256];
 };

@@ -147,6 +147,11 @@ enum { IMREAD_GRAYSCALE = 0 };
 Mat imread(const std::string &path, int flags = IMREAD_GRAYSCALE);
 Mat imdecode(const std::vector<uchar> &buf, int flags = IMREAD_GRAYSCALE);
 Mat imdecode(const uchar *data, size_t size, int flags = IMREAD_GRAYSCALE);
+// debug write-out (AnalyzerUnit.cpp:237,354-365; L3Localizer.cpp:236-257,448): 8-bit grey PNG, or 8-bit palettised BMP
+// when the name ends in .bmp; false when the file cannot be written (like cv::imwrite into a missing directory)
+bool imwrite(const std::string &path, const Mat &img);
+// 1-pixel outline of `r` (the part inside the image), cv::rectangle(img, r, color, 1, 8, 0) for a grey image
+void rectangle(Mat &img, const Rect &r, const Scalar &color, int thickness = 1, int lineType = 8, int shift = 0);
 
 } // namespace cv
 

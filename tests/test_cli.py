@@ -133,3 +133,62 @@ def test_cli_run_matches_oracle_text(tmp_path, oracle):
     assert "batched detect:" in so and txt == expected
     txt, so = cli("zip_per_event", ["--per-event"], zipped=True, env={"ABUB_THREADS": "2"})
     assert txt == expected
+
+
+@pytest.mark.gpu
+def test_cli_debug_image_write_out(tmp_path, oracle):
+    """--debug 101 (localizer + analyzer debug digits, AutoBubStart3.cpp:142): the per-event path dumps the images the
+    reference dumps -- DebugPeek/ev<id>_cam<c>_{000_AvgImage,00_PreTrigFrame,0_TrigFrame,02_OvrThe6Sigma,
+    3_OtsuThresholded,4_BubbleDetected}.png and $HOME/test/abub_debug/ev_<id>_[pos_|neg_|pos_filter_|neg_filter_]<frame>
+    -- and they hold what the oracle computes for those stages."""
+    W, H, F, run_id = 320, 128, 41, "20200925_2"
+    rd = os.path.join(tmp_path, "data", run_id)
+    stacks = []
+    for e in range(3):
+        spec = synth.EventSpec(F, t0=14 + e, bubbles=[(100 + 40 * e, 60, 40)])
+        st = synth.render_event(W, H, spec, 700 + e, 0)
+        stacks.append(st)
+        d = os.path.join(rd, str(e), "Images")
+        os.makedirs(d)
+        for k in range(F):
+            Image.fromarray(st[k]).save(os.path.join(d, f"cam0_image{30 + k}.png"))
+    home = os.path.join(tmp_path, "home")
+    os.makedirs(os.path.join(home, "test", "abub_debug"))
+    os.makedirs(os.path.join(tmp_path, "DebugPeek"))
+    out = os.path.join(tmp_path, "out")
+    os.makedirs(out)
+    e = dict(os.environ, ABUB_NUM_CAMS="1", HOME=home)
+    p = subprocess.run([EXE, "-d", os.path.join(tmp_path, "data"), "-r", run_id, "-o", out, "-D", "40l-19", "--debug", "101",
+                        "-e", "1"], capture_output=True, text=True, env=e, timeout=300, cwd=tmp_path)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    mu, sg = oracle.welford(np.concatenate([s[:2] for s in stacks]))
+    a = oracle.Analyzer(stacks[1], mu, sg, 6)
+    staged, state, bubbles = a.any_cam_analysis()
+    a.close()
+    assert staged == 0 and "Entropy of BkgSub" in p.stdout and "-----Start ev 1, cam 0" in p.stdout
+    t = state["trig"]
+
+    def png(path):
+        return np.asarray(Image.open(path).convert("L"))
+
+    peek = os.path.join(tmp_path, "DebugPeek", "ev1_cam0_")
+    assert np.array_equal(png(peek + "000_AvgImage.png"), mu)
+    assert np.array_equal(png(peek + "0_TrigFrame.png"), stacks[1][t])
+    assert np.array_equal(png(peek + "00_PreTrigFrame.png"), stacks[1][t - 2])
+    D = oracle.process_frame(stacks[1][t], stacks[1][t - 2], sg)
+    assert np.array_equal(png(peek + "02_OvrThe6Sigma.png"), D)
+    thr = max(state["loc_thres"], oracle.otsu(oracle.hist256(np.where(D > state["loc_thres"], D, 0))))
+    assert np.array_equal(png(peek + "3_OtsuThresholded.png"), np.where(D > thr, 255, 0).astype(np.uint8))
+    marked = png(peek + "4_BubbleDetected.png")
+    d0 = bubbles[0]["desc"][0]
+    assert marked[d0["y"], d0["x"]] == 255 and marked[d0["y"] + d0["h"] - 1, d0["x"] + d0["w"] - 1] == 255
+    dbg = os.path.join(home, "test", "abub_debug", "ev_1_")
+    for k in (1, t):  # the search dumps every frame it evaluates (two-frame offset: ref = max(k - 2, 0))
+        name = f"cam0_image{30 + k}.png"
+        ref = max(k - 2, 0)
+        assert np.array_equal(png(dbg + name), oracle.process_frame(stacks[1][k], stacks[1][ref], sg))
+        c, r, s6 = stacks[1][k].astype(int), stacks[1][ref].astype(int), 6 * sg.astype(int)
+        assert np.array_equal(png(dbg + "pos_" + name), np.clip(c - r - s6, 0, 255))
+        assert np.array_equal(png(dbg + "neg_" + name), np.clip(r - c - s6, 0, 255))
+        assert os.path.exists(dbg + "pos_filter_" + name) and os.path.exists(dbg + "neg_filter_" + name)
+    assert not os.path.exists(dbg + f"cam0_image{30 + t + 3}.png")  # nothing past the look-ahead

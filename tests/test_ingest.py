@@ -185,3 +185,19 @@ def test_run_from_disk_equals_run_from_memory(tmp_path, oracle):
         ref = a.any_cam_analysis()
         a.close()
         assert out[e][0] == ref[0] and out[e][1] == ref[1]
+
+
+@pytest.mark.parametrize("ext", ["png", "bmp"])
+def test_imwrite_round_trip(tmp_path, ext):
+    """Debug image write-out (AnalyzerUnit.cpp:237, L3Localizer.cpp:236-257): what cvlite writes, Pillow and cvlite's
+    own decoder read back unchanged; a missing directory gives False like cv::imwrite."""
+    from PIL import Image
+
+    rs = np.random.RandomState(4)
+    for shape in [(37, 53), (1, 1), (64, 100)]:
+        img = rs.randint(0, 256, shape).astype(np.uint8)
+        path = os.path.join(tmp_path, f"dbg_{shape[0]}.{ext}")
+        assert host.imwrite(path, img)
+        assert np.array_equal(np.asarray(Image.open(path).convert("L")), img)
+        assert np.array_equal(host.imdecode(open(path, "rb").read()), img)
+    assert not host.imwrite(os.path.join(tmp_path, "missing_dir", "x." + ext), img)
