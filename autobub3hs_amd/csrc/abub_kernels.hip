@@ -574,7 +574,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER
 //       per job and chunk) and computed exactly BY THE SAME WAVE once its scan is over (k2b_tail: the four pixels
 //       straight from the definition, one lane per group) -- no list in global memory, no second kernel.  A chunk
 //       whose rows keep exceeding 32 suspects (one row of the row machine costs about 30 exact groups), or that
-//       would overflow its LDS list, hands its REMAINING rows over.
+//       would overflow its LDS list, hands its REMAINING rows over.  (Handing over only the next K2B_SUB rows and
+//       scanning on behind them was measured equal in time and cost a wave of occupancy at W = 1680.)
 //   k2_rows (list mode)
 //       the full row machine on the handed-over row ranges, cut into pieces of K2B_SUB rows so that the few of them
 //       spread over the chip instead of serialising behind one wave each.
@@ -606,6 +607,23 @@ struct K2BoundJob { // per-job state of the bound recurrence and of its suspect 
     uint32_t npend, hot, jidx;
     int handover; // < 0: scanning; >= 0: first output row left to the row machine (or "nothing to do")
 };
+
+// hand the rows [y, y1) of `unit` to the row machine, in pieces of K2B_SUB rows (capacity: see launch_k2_rows)
+__device__ __forceinline__ void k2b_hand_over(uint2 *__restrict__ units, uint32_t *__restrict__ nunits, uint32_t unit, int y, int y1,
+                                              int lane)
+{
+    const int np = (y1 - y + K2B_SUB - 1) / K2B_SUB;
+    if (np <= 0)
+        return;
+    uint32_t base = 0;
+    if (lane == 0)
+        base = atomicAdd(nunits, (uint32_t)np);
+    base = __builtin_amdgcn_readfirstlane(base);
+    for (int i = lane; i < np; i += 64) {
+        const int a = y + i * K2B_SUB, b = a + K2B_SUB < y1 ? a + K2B_SUB : y1;
+        units[base + i] = make_uint2(unit, (uint32_t)a | ((uint32_t)b << 16));
+    }
+}
 
 // one input row of one job: group masses m[] -> bound of output row y; suspects go to the job's LDS list.
 // Everything that steers control flow is read through SGPRs (ballots, s_bcnt1), so the scan loops compile to scalar
@@ -657,7 +675,7 @@ __device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const int par, const
     }
     J.hot += total > 32u; // one row of the row machine costs about as much as 30 exact groups
     if (J.hot >= 4u || J.npend + total > budget) {
-        J.handover = y;
+        J.handover = y; // dense rows (or the LDS list is full): the rest of the chunk goes to the row machine
         return;
     }
     const uint32_t code0 = (uint32_t)y * ngroups + (uint32_t)lane * NDW;
@@ -779,23 +797,6 @@ __device__ __forceinline__ void k2b_tail(const uint32_t *pend, uint32_t npend, c
             for (int k = 0; k < 4; k++)
                 compact_put(cp, pos, Dv[k], pix0 + k);
         }
-    }
-}
-
-// hand the rows [y, y1) of `unit` to the row machine, in pieces of K2B_SUB rows (capacity: see launch_k2_rows)
-__device__ __forceinline__ void k2b_hand_over(uint2 *__restrict__ units, uint32_t *__restrict__ nunits, uint32_t unit, int y, int y1,
-                                              int lane)
-{
-    const int np = (y1 - y + K2B_SUB - 1) / K2B_SUB;
-    if (np <= 0)
-        return;
-    uint32_t base = 0;
-    if (lane == 0)
-        base = atomicAdd(nunits, (uint32_t)np);
-    base = __builtin_amdgcn_readfirstlane(base);
-    for (int i = lane; i < np; i += 64) {
-        const int a = y + i * K2B_SUB, b = a + K2B_SUB < y1 ? a + K2B_SUB : y1;
-        units[base + i] = make_uint2(unit, (uint32_t)a | ((uint32_t)b << 16));
     }
 }
 
@@ -1907,9 +1908,9 @@ __global__ __launch_bounds__(64) void k3_rows(const uint8_t *__restrict__ frames
 // box sums that touch a pair's columns in one row are bounded by M = left group + own pair + right group (edge groups
 // replicated: the reflected column lies inside them), and S <= M(y-1) + M(y) + M(y+1).  Rows where no pair reaches 5
 // are proven zero with one ballot (isolated hot pixels -- sigma = 0 leaves |f - mu| of a few ADU -- stay far below).
-// Suspect groups are remembered in LDS and computed exactly by the same wave afterwards (k3s_tail); a chunk with
-// too many of them (the bubble itself) hands its remaining rows to the row machine in pieces of K2B_SUB rows.
-#define K3S_PEND 256 /* suspects per (job, chunk) kept in LDS */
+// Suspect groups are remembered in LDS and computed exactly by the same wave afterwards (k3s_tail); where there are
+// too many of them (a large bubble) the next K2B_SUB rows go to the row machine as a piece and the scan resumes behind.
+#define K3S_PEND 512 /* suspects per (job, chunk) kept in LDS: the footprint of a tracked bubble fits */
 
 template <int NDW>
 struct K3ScanJob {
@@ -1917,7 +1918,7 @@ struct K3ScanJob {
     static constexpr int NG = (NDW + GS - 1) / GS;
     uint32_t Mh[2][NG]; // M of the last two input rows, by row parity (the row loops are unrolled by two)
     uint32_t npend, hot;
-    int handover; // < 0: scanning; >= 0: first output row left to the row machine
+    int skipTo; // output rows below this one belong to the row machine (a piece was handed over) or are not this job's
 };
 
 // exact O for the four pixels of every remembered group (L3Localizer.cpp:779-785): one lane per group
@@ -1942,6 +1943,9 @@ __device__ __forceinline__ void k3s_tail(const uint32_t *pend, uint32_t npend, c
         if (e < npend) {
             const uint32_t code = pend[e];
             const int y = (int)(code / ngroups), x0 = (int)(code % ngroups) * 4;
+            // interior groups read their 6-pixel window as three aligned dwords per array and row (the pixels x0-1 ..
+            // x0+4 are bytes 3 .. 8 of the 12 bytes from x0-4); the two edge groups (reflected columns) go byte by byte
+            const bool interior = x0 >= 4 && x0 + 8 <= W;
             int xs[6];
 #pragma unroll
             for (int j = 0; j < 6; j++)
@@ -1951,12 +1955,27 @@ __device__ __forceinline__ void k3s_tail(const uint32_t *pend, uint32_t npend, c
             for (int i = 0; i < 3; i++) {
                 const size_t ro = (size_t)reflect101(y - 1 + i, H) * W;
                 int o[6];
+                if (interior) {
+                    const uint32_t *pf = reinterpret_cast<const uint32_t *>(f + ro + x0 - 4);
+                    const uint32_t *pm = reinterpret_cast<const uint32_t *>(m + ro + x0 - 4);
+                    const uint32_t *ps = reinterpret_cast<const uint32_t *>(sg + ro + x0 - 4);
+                    const uint32_t fw[3] = {pf[0], pf[1], pf[2]}, mw[3] = {pm[0], pm[1], pm[2]}, sw[3] = {ps[0], ps[1], ps[2]};
 #pragma unroll
-                for (int j = 0; j < 6; j++) {
-                    int a = (int)f[ro + xs[j]] - (int)m[ro + xs[j]];
-                    a = a < 0 ? -a : a;
-                    a -= (int)sg[ro + xs[j]];
-                    o[j] = a < 0 ? 0 : a;
+                    for (int j = 0; j < 6; j++) {
+                        const int q = (3 + j) >> 2, sh = 8 * ((3 + j) & 3);
+                        int a = (int)((fw[q] >> sh) & 0xff) - (int)((mw[q] >> sh) & 0xff);
+                        a = a < 0 ? -a : a;
+                        a -= (int)((sw[q] >> sh) & 0xff);
+                        o[j] = a < 0 ? 0 : a;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        int a = (int)f[ro + xs[j]] - (int)m[ro + xs[j]];
+                        a = a < 0 ? -a : a;
+                        a -= (int)sg[ro + xs[j]];
+                        o[j] = a < 0 ? 0 : a;
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < 4; q++)
@@ -1994,7 +2013,8 @@ __global__ __launch_bounds__(64) void k3_bound_scan(const uint8_t *__restrict__ 
                                                     int rows_per_chunk, int nchunks, uint32_t *__restrict__ hist,
                                                     uint8_t *__restrict__ img, uint2 *__restrict__ pieces,
                                                     uint32_t *__restrict__ npieces, const int32_t *__restrict__ cthr,
-                                                    uint32_t *pairs, uint32_t pcap, uint32_t *pcount, uint32_t slot_base)
+                                                    uint32_t *pairs, uint32_t pcap, uint32_t *pcount, uint32_t slot_base,
+                                                    uint32_t budget)
 {
     constexpr int NP = 2 * NDW;
     constexpr int NG = K3ScanJob<NDW>::NG, GS = K3ScanJob<NDW>::GS;
@@ -2043,7 +2063,7 @@ __global__ __launch_bounds__(64) void k3_bound_scan(const uint8_t *__restrict__ 
         for (int g = 0; g < NG; g++)
             J[t].Mh[0][g] = J[t].Mh[1][g] = 0;
         J[t].npend = J[t].hot = 0;
-        J[t].handover = t < k ? -1 : 0x7fffffff;
+        J[t].skipTo = t < k ? 0 : 0x7fffffff;
     }
     const int T = y1 - y0 + 2; // input rows r = y0-1 .. y1 (reflected at the image border)
     const uint32_t ngroups = (uint32_t)W / 4;
@@ -2068,12 +2088,6 @@ __global__ __launch_bounds__(64) void k3_bound_scan(const uint8_t *__restrict__ 
     K3S_LOAD(0, reflect101(y0 - 1, H));
     const int Tpad = (T + 1) & ~1;
     for (int t0 = 0; t0 < Tpad; t0 += 2) {
-        bool all_done = true;
-#pragma unroll
-        for (int t = 0; t < KF; t++)
-            all_done = all_done && J[t].handover >= 0;
-        if (all_done)
-            break;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int tt = t0 + u; // input row r = y0 - 1 + tt; completes the bound of output row y = y0 + tt - 2
@@ -2085,7 +2099,7 @@ __global__ __launch_bounds__(64) void k3_bound_scan(const uint8_t *__restrict__ 
             const bool emit = tt >= 2 && tt < T;
 #pragma unroll
             for (int t = 0; t < KF; t++) {
-                if (J[t].handover >= 0)
+                if (t >= k)
                     continue;
                 // group masses of O in this input row (u16 halves: <= 2 * 255 each)
                 uint32_t mg[NDW];
@@ -2114,7 +2128,7 @@ __global__ __launch_bounds__(64) void k3_bound_scan(const uint8_t *__restrict__ 
                     worst |= B[g];
                 }
                 const bool unsure = active && ((worst & 0xffffu) + (worst >> 16)) >= 5u; // (OR over-estimates: verified below)
-                if (emit && __builtin_amdgcn_ballot_w64(unsure)) {
+                if (emit && y >= J[t].skipTo && __builtin_amdgcn_ballot_w64(unsure)) {
                     // ---- rare: some group of this output row cannot be proven zero ------------------------
                     unsigned long long bm[NG];
                     bool mine[NG];
@@ -2127,8 +2141,13 @@ __global__ __launch_bounds__(64) void k3_bound_scan(const uint8_t *__restrict__ 
                         total += (uint32_t)nq * (uint32_t)__builtin_popcountll(bm[g]);
                     }
                     J[t].hot += total > 32u;
-                    if (J[t].hot >= 4u || J[t].npend + total > K3S_PEND) {
-                        J[t].handover = y;
+                    if (J[t].hot >= 4u || J[t].npend + total > budget) {
+                        // dense rows (or the LDS list is full): the next K2B_SUB rows go to the row machine as one
+                        // piece; the scan goes on underneath and takes over again after them
+                        const int ye = y + K2B_SUB < y1 ? y + K2B_SUB : y1;
+                        k2b_hand_over(pieces, npieces, (uint32_t)(j0 + t), y, ye, lane);
+                        J[t].skipTo = ye;
+                        J[t].hot = 0;
                     } else {
                         const uint32_t code0 = (uint32_t)y * ngroups + (uint32_t)lane * NDW;
                         uint32_t base = J[t].npend;
@@ -2150,7 +2169,7 @@ __global__ __launch_bounds__(64) void k3_bound_scan(const uint8_t *__restrict__ 
                         J[t].npend = base;
                     }
                 }
-                if (STORE && emit && J[t].handover < 0 && active) {
+                if (STORE && emit && y >= J[t].skipTo && active) {
                     // the scan is responsible for this row: zeros now, the tail overwrites its suspect groups
                     uint32_t *po = reinterpret_cast<uint32_t *>(obase[t] + (ptrdiff_t)y * W);
 #pragma unroll
@@ -2164,8 +2183,6 @@ __global__ __launch_bounds__(64) void k3_bound_scan(const uint8_t *__restrict__ 
 #pragma unroll
     for (int t = 0; t < KF; t++) {
         if (t < k) {
-            if (J[t].handover >= 0)
-                k2b_hand_over(pieces, npieces, (uint32_t)(j0 + t), J[t].handover, y1, lane);
             Compact cp;
             cp.pairs = COMPACT ? pairs : nullptr;
             cp.count = pcount;
@@ -2207,9 +2224,17 @@ static int launch_k3_rows(const uint8_t *frames, const uint8_t *mu, const uint8_
         uint2 *pieces = (uint2 *)(scr + 256);
         HIPCHK(hipMemsetAsync(counter, 0, sizeof(uint32_t), st));
         const dim3 sgrid((unsigned)((size_t)((njobs + KF - 1) / KF) * nchunks));
+        static int k3b = -1;
+        if (k3b < 0) {
+            const char *e = getenv("ABUB_K3_BUDGET"); // suspects a (job, chunk) may remember before it hands a piece over
+            k3b = e ? atoi(e) : K3S_PEND;
+            if (k3b < 0 || k3b > K3S_PEND)
+                k3b = K3S_PEND;
+        }
+        const uint32_t k3budget = (uint32_t)k3b;
 #define K3S_LAUNCH(ST, CO)                                                                                          \
     hipLaunchKernelGGL((k3_bound_scan<NDW, KF, ST, CO>), sgrid, dim3(64), 0, st, frames, mu, sigma6, jobs, njobs, W, \
-                       H, R, nchunks, hist, img, pieces, counter, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base)
+                       H, R, nchunks, hist, img, pieces, counter, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base, k3budget)
         if (ca.cthr) {
             if (img)
                 K3S_LAUNCH(true, true);
@@ -2271,9 +2296,20 @@ static int posttrig_impl(const uint8_t *frames, const uint8_t *mu, const uint8_t
     HIPCHK(hipMemsetAsync(hist, 0, (size_t)njobs * 256 * sizeof(uint32_t), st));
     int ndw = pick_ndw(W);
     if (ndw) {
+        // waves of the launch = (groups of jobs one wave serves) x chunks: enough of them (>= ~8k, several rounds of the
+        // chip's wave slots) that the exact tails of early waves run under the scans of later ones
+        const int kf = k3_scan_enabled() ? (ndw <= 5 ? 5 : (ndw <= 7 ? 4 : 3)) : 1;
+        const long long ngrp = (njobs + kf - 1) / kf;
         int nch = 8;
-        if ((long long)njobs * nch < 8192)
-            nch = (8192 + njobs - 1) / njobs;
+        if (ngrp * nch < 8192)
+            nch = (int)((8192 + ngrp - 1) / ngrp);
+        static int k3chunks = -1;
+        if (k3chunks < 0) {
+            const char *e = getenv("ABUB_K3_CHUNKS"); // tuning knob: chunks per frame (0 = automatic)
+            k3chunks = e ? atoi(e) : 0;
+        }
+        if (k3chunks > 0)
+            nch = k3chunks;
         nch = (nch + 7) / 8 * 8;
         int R = (H + nch - 1) / nch;
         if (R < 16)

@@ -1,0 +1,9 @@
+export LD_LIBRARY_PATH=$PWD/autobub3hs_amd:$LD_LIBRARY_PATH
+O=gpurun_out/r2t; mkdir -p $O
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
+timeout -k 10 600 python bench.py --micro-frames 0 --no-cpu-baseline --ingest-events 0 --stream-steps 0 2>/dev/null | python3 -c "
+import json,sys
+r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('value',r['value'],'ms',r['ms_per_step'],'roof',r['roofline']['frac'],r['roofline']['ms_per_launch'],r['config']['latency_one_step_at_a_time_ms'])"
+timeout -k 10 600 python bench.py --width 1680 --height 1050 --micro-frames 0 --no-cpu-baseline --ingest-events 0 --stream-steps 0 2>/dev/null | python3 -c "
+import json,sys
+r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('1680 value',r['value'],'ms',r['ms_per_step'],'roof',r['roofline']['frac'],r['roofline']['ms_per_launch'],r['config']['latency_one_step_at_a_time_ms'])"
