@@ -588,7 +588,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER
 // lane's groups, which can only over-estimate, the per-group test on a suspicious row folds exactly.
 // ------------------------------------------------------------------------------------------------
 #define K2B_PEND 512 /* suspects per (job, chunk) kept in LDS; also >= the groups of one row (W/4 <= 512) */
-#define K2B_SUB 32   /* rows per handed-over piece */
+#ifndef K2B_SUB
+#define K2B_SUB 32 /* rows per handed-over piece */
+#endif
 
 template <int NDW>
 struct K2BoundJob { // per-job state of the bound recurrence and of its suspect list (all wave-uniform but b*/Mprev)

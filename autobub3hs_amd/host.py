@@ -411,10 +411,12 @@ class PipelineRing:
         for p in self.pipes:
             p.close()
 
-    def run_batches(self, batches, mu, sigma6, stream=0, on_done=None):
-        """batches: sequence of frame slabs (device tensors / pointers, each [E][C][F][H][W]).  Returns the per-batch
-        timing dicts in completion order; `on_done(k, pipeline)` is called on the driving thread right after batch
-        k finished, while its results are still the pipeline's current ones."""
+    def run_batches(self, batches, mu, sigma6, stream=0, on_done=None, host=False):
+        """batches: sequence of frame slabs (device tensors / pointers, each [E][C][F][H][W]); with host=True they are
+        HOST slabs (pinned for full PCIe rate) and every pipeline streams its batch in (Pipeline.run_host), so the upload
+        of one run overlaps the detect stages of the previous one (BASELINE configs[4]: many runs streamed host -> HBM).
+        Returns the per-batch timing dicts in completion order; `on_done(k, pipeline)` is called on the driving thread
+        right after batch k finished, while its results are still the pipeline's current ones."""
         import threading
 
         n = len(self.pipes)
@@ -430,7 +432,10 @@ class PipelineRing:
                 except ImportError:
                     pass
                 for k in range(i, len(batches), n):
-                    self.pipes[i].run(batches[k], mu, sigma6, stream)
+                    if host:
+                        self.pipes[i].run_host(batches[k], mu, sigma6)
+                    else:
+                        self.pipes[i].run(batches[k], mu, sigma6, stream)
                     if on_done:
                         on_done(k, self.pipes[i])
                     with lock:

@@ -47,8 +47,9 @@ def parse(argv=None):
     ap.add_argument("--threads", type=int, default=16, help="host threads of the per-event state machines")
     ap.add_argument("--inflight", type=int, default=3,
                     help="steps in flight at once (each on its own pipeline object and host thread)")
-    ap.add_argument("--stream-steps", type=int, default=2,
-                    help="extra steps with the run uploaded from pinned host memory (PCIe-inclusive rate; 0 = skip)")
+    ap.add_argument("--stream-steps", type=int, default=10,
+                    help="runs streamed from pinned host memory, two in flight (BASELINE configs[4] on this GPU: PCIe-inclusive "
+                         "rate, reported in config only; 0 = skip)")
     ap.add_argument("--min-seconds", type=float, default=2.0,
                     help="repeat the timed K-step block until this much time has been measured (0 = one block)")
     ap.add_argument("--max-blocks", type=int, default=400)
@@ -303,14 +304,18 @@ def main():
         h_slab = torch.empty(slab.shape, dtype=torch.uint8).pin_memory()
         h_slab.copy_(slab)
         torch.cuda.synchronize()
-        pipe.run_host(h_slab, mu_d, s6_d)  # warm-up (allocates the pipeline-owned slab)
-        assert pipe.summary() == fingerprint, "streamed run differs from the resident run"
+        nstream = min(2, len(pipes))
+        sring = host.PipelineRing.__new__(host.PipelineRing)  # the first pipelines of the ring, each with its own HBM slab
+        sring.device, sring.pipes = local, pipes[:nstream]
+        sring.run_batches([h_slab] * nstream, mu_d, s6_d, host=True)  # warm-up (allocates the pipeline-owned slabs)
+        assert all(p_.summary() == fingerprint for p_ in sring.pipes), "streamed run differs from the resident run"
         ts = time.perf_counter()
-        for _ in range(args.stream_steps):
-            pipe.run_host(h_slab, mu_d, s6_d)
+        sring.run_batches([h_slab] * args.stream_steps, mu_d, s6_d, host=True)
         tstream = (time.perf_counter() - ts) / args.stream_steps
-        pcie = {"frames_per_s": S * F / tstream, "ms_per_run": tstream * 1e3,
-                "GBps_host_to_hbm": S * F * P / tstream / 1e9}
+        pcie = {"frames_per_s": S * F / tstream, "ms_per_run": tstream * 1e3, "runs": args.stream_steps, "runs_in_flight": nstream,
+                "GBps_host_to_hbm": S * F * P / tstream / 1e9,
+                "note": "every run starts in pinned host memory; stack groups are uploaded with hipMemcpyAsync on a copy stream "
+                        "while earlier groups / the previous run are in their detect stages"}
         del h_slab
     out["config"]["pcie_inclusive"] = pcie
 
