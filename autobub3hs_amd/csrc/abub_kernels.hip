@@ -592,6 +592,81 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER
 #define K2B_SUB 32 /* rows per handed-over piece */
 #endif
 
+// Lane -> pixel mapping of the scan kernels.  A row is cut into segments; in segment s every lane owns segK(s)
+// consecutive dwords (4-pixel groups): lane L the groups [gbase[s] + segK(s) * L, + segK(s)).
+//   blocked (SPLIT = false): one segment of NDW dwords per lane -- the row machine's mapping; a lane's dwordx4 + dword
+//                            loads then sit at a 4 * NDW byte stride, so every load instruction touches every line
+//                            of the row partially;
+//   split   (SPLIT = true):  NDW = 5 -> {4,1}, 6 -> {4,2}, 7 -> {4,2,1} dwords: each load instruction (dwordx4, dwordx2,
+//                            dword) covers ONE contiguous span of the row with whole 16 / 8 / 4-byte pieces per lane.
+//                            tools/rowload_bench.cpp: the chained scan's access pattern is 3 % cheaper at W = 1280 and
+//                            12 % at W = 1680 this way.  Only the last segment may have idle lanes.
+// The suspect codes are global group indices and hand-overs are row ranges, so the row machine (always blocked) and
+// the exact tails do not care which mapping the scan used.
+template <int NDW, bool SPLIT>
+struct ScanMap {
+    static constexpr int NSEG = !SPLIT ? 1 : (NDW == 7 ? 3 : 2);
+    static __device__ __host__ constexpr int segK(int s) { return !SPLIT ? NDW : (s == 0 ? 4 : (NDW == 5 ? 1 : (NDW == 6 ? 2 : (s == 1 ? 2 : 1)))); }
+    static __device__ __host__ constexpr int segD0(int s) { return !SPLIT ? 0 : (s == 0 ? 0 : (s == 1 ? 4 : 6)); }
+    static __device__ __host__ constexpr int segOf(int d) { return !SPLIT ? 0 : (d < 4 ? 0 : (d < 6 && NDW != 5 ? 1 : NSEG - 1)); }
+    int n[NSEG];     // active lanes of the segment
+    int gbase[NSEG]; // its first 4-pixel group
+    __device__ __forceinline__ void init(int W)
+    {
+        const int ng = W / 4;
+        if (!SPLIT) {
+            n[0] = ng / NDW;
+            gbase[0] = 0;
+        } else {
+            int g = 0;
+#pragma unroll
+            for (int s = 0; s < NSEG; s++) {
+                gbase[s] = g;
+                const int left = (ng - g) / segK(s);
+                n[s] = left < 64 ? left : 64;
+                g += 64 * segK(s);
+            }
+        }
+    }
+    // byte offset of the lane's piece of segment s in a row (idle lanes shadow lane 0: valid address, results unused)
+    __device__ __forceinline__ int byteoff(int s, int lane) const { return 4 * (gbase[s] + segK(s) * (lane < n[s] ? lane : 0)); }
+    __device__ __forceinline__ void load(uint32_t (&r)[NDW], const uint8_t *__restrict__ row, int lane) const
+    {
+#pragma unroll
+        for (int s = 0; s < NSEG; s++) {
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(row + byteoff(s, lane));
+#pragma unroll
+            for (int d = 0; d < segK(s); d++)
+                r[segD0(s) + d] = p[d];
+        }
+    }
+    __device__ __forceinline__ void store_zero(uint8_t *__restrict__ row, int lane) const
+    {
+#pragma unroll
+        for (int s = 0; s < NSEG; s++)
+            if (lane < n[s]) {
+                uint32_t *p = reinterpret_cast<uint32_t *>(row + byteoff(s, lane));
+#pragma unroll
+                for (int d = 0; d < segK(s); d++)
+                    p[d] = 0;
+            }
+    }
+};
+// the split decomposition exists for 256 < W / 4 <= 448 groups: returns the NDW of the segment set, or 0
+static int split_ndw(int W)
+{
+    if (W <= 0 || (W & 3))
+        return 0;
+    const int ng = W / 4;
+    if (ng > 256 && ng <= 320)
+        return 5;
+    if (ng > 320 && ng <= 384 && ((ng - 256) & 1) == 0)
+        return 6;
+    if (ng > 384 && ng <= 448)
+        return 7;
+    return 0;
+}
+
 template <int NDW>
 struct K2BoundJob { // per-job state of the bound recurrence and of its suspect list (all wave-uniform but b*/Mprev)
     // The recurrence runs on PAIRS of 4-pixel groups (8 columns, the last one alone when NDW is odd): the taps of a
@@ -604,7 +679,9 @@ struct K2BoundJob { // per-job state of the bound recurrence and of its suspect 
     static constexpr int NG = (NDW + GS - 1) / GS;
     // vertical 1-4-6-4-1 of the group masses as four cascaded two-tap sums (binomial = (1 + z^-1)^4): per group four
     // plain 32-bit adds and no shift / multiply; P[k][parity] = output of stage k at the previous row of that parity
-    // (the row loops are unrolled by two, so nothing is ever copied)
+    // (the row loops are unrolled by two, so nothing is ever copied).  Wide rows (NDW >= 6) keep the state in four
+    // in-place accumulators instead (P[k][0]): 16 instead of 32 registers per job there, which is a wave of occupancy.
+    static constexpr bool CASCADE = NDW <= 5;
     uint32_t P[4][2][NG];
     uint32_t npend, hot, jidx;
     int handover; // < 0: scanning; >= 0: first output row left to the row machine (or "nothing to do")
@@ -630,38 +707,79 @@ __device__ __forceinline__ void k2b_hand_over(uint2 *__restrict__ units, uint32_
 // one input row of one job: group masses m[] -> bound of output row y; suspects go to the job's LDS list.
 // Everything that steers control flow is read through SGPRs (ballots, s_bcnt1), so the scan loops compile to scalar
 // branches.
-template <int NDW>
-__device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const int par, const uint32_t (&m)[NDW], bool emit, int y,
-                                        bool active, bool first_lane, bool last_lane, int lane, uint32_t ngroups,
-                                        uint32_t budget, uint32_t *pend)
+template <int NDW, bool SPLIT>
+__device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const int par, uint32_t (&m)[NDW], bool emit, int y,
+                                        const ScanMap<NDW, SPLIT> &map, int lane, uint32_t ngroups, uint32_t budget,
+                                        uint32_t *pend)
 {
-    uint32_t mL = __builtin_amdgcn_update_dpp(0u, m[NDW - 1], DPP_WAVE_SHR1, 0xf, 0xf, false);
-    uint32_t mR = __builtin_amdgcn_update_dpp(0u, m[0], DPP_WAVE_SHL1, 0xf, 0xf, false);
-    mL = first_lane ? m[0] : mL;
-    mR = last_lane ? m[NDW - 1] : mR;
+    using Map = ScanMap<NDW, SPLIT>;
+    constexpr int NSEG = Map::NSEG;
+    // masses of the groups left of each segment's first and right of its last group: neighbour lanes inside a
+    // segment (DPP), the adjacent segment's end at lane 0 / the last lane (one v_readlane), the replicated own edge
+    // group at the image border (the reflected column lies inside it)
+    bool act[NSEG];
+    uint32_t mLs[NSEG], mRs[NSEG];
+#pragma unroll
+    for (int s = 0; s < NSEG; s++) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        act[s] = lane < map.n[s];
+    }
+    if (SPLIT) { // idle lanes of the (partial) last segment carry lane 0's pixels: their masses must not count
+#pragma unroll
+        for (int d = Map::segD0(NSEG - 1); d < NDW; d++)
+            m[d] = act[NSEG - 1] ? m[d] : 0u;
+    }
+#pragma unroll
+    for (int s = 0; s < NSEG; s++) {
+        const int dF = Map::segD0(s), dL = Map::segD0(s) + Map::segK(s) - 1;
+        uint32_t l = __builtin_amdgcn_update_dpp(0u, m[dL], DPP_WAVE_SHR1, 0xf, 0xf, false);
+        uint32_t r = __builtin_amdgcn_update_dpp(0u, m[dF], DPP_WAVE_SHL1, 0xf, 0xf, false);
+        uint32_t edgeL = m[dF], edgeR = m[dL];
+        if (s > 0)
+            edgeL = __builtin_amdgcn_readlane(m[Map::segD0(s - 1) + Map::segK(s - 1) - 1], 63); // (inner segments are full)
+        if (s + 1 < NSEG)
+            edgeR = __builtin_amdgcn_readlane(m[Map::segD0(s + 1)], 0);
+        mLs[s] = lane == 0 ? edgeL : l;
+        mRs[s] = lane == map.n[s] - 1 ? edgeR : r;
+    }
     constexpr int NG = K2BoundJob<NDW>::NG;
     constexpr int GS = K2BoundJob<NDW>::GS;
+    static_assert(GS == 2 || NDW == 1, "the segment tables assume pairs of groups");
     uint32_t B[NG];
     uint32_t worst = 0; // OR of the bounds: each half >= that half of every group's bound (cheaper than a packed max)
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         const int g0 = GS * g, g1 = GS * g + GS - 1 < NDW ? GS * g + GS - 1 : NDW - 1; // first and last 4-pixel group
+        const int sg = Map::segOf(g0);
         uint32_t own = m[g0];
 #pragma unroll
         for (int q = g0 + 1; q <= g1; q++)
             own += m[q];
-        const uint32_t M = (g0 ? m[g0 - 1] : mL) + own + (g1 + 1 < NDW ? m[g1 + 1] : mR);
-        const uint32_t s1 = M + J.P[0][par ^ 1][g];
-        const uint32_t s2 = s1 + J.P[1][par ^ 1][g];
-        const uint32_t s3 = s2 + J.P[2][par ^ 1][g];
-        B[g] = s3 + J.P[3][par ^ 1][g];
-        J.P[0][par][g] = M;
-        J.P[1][par][g] = s1;
-        J.P[2][par][g] = s2;
-        J.P[3][par][g] = s3;
+        const bool segStart = g0 == Map::segD0(sg), segEnd = g1 == Map::segD0(sg) + Map::segK(sg) - 1;
+        const uint32_t M = (segStart ? mLs[sg] : m[g0 - 1]) + own + (segEnd ? mRs[sg] : m[g1 + 1]);
+        if (K2BoundJob<NDW>::CASCADE) {
+            const uint32_t s1 = M + J.P[0][par ^ 1][g];
+            const uint32_t s2 = s1 + J.P[1][par ^ 1][g];
+            const uint32_t s3 = s2 + J.P[2][par ^ 1][g];
+            B[g] = s3 + J.P[3][par ^ 1][g];
+            J.P[0][par][g] = M;
+            J.P[1][par][g] = s1;
+            J.P[2][par][g] = s2;
+            J.P[3][par][g] = s3;
+        } else { // four in-place accumulators (b0, b1, b2, previous M): half the registers, a shift and a multiply more
+            B[g] = J.P[0][0][g] + M;
+            const uint32_t M4 = M << 2;
+            J.P[0][0][g] = J.P[1][0][g] + M4;
+            J.P[1][0][g] = pk_madk<6>(M, J.P[2][0][g]);
+            J.P[2][0][g] = J.P[3][0][g] + M4;
+            J.P[3][0][g] = M;
+        }
+        if (sg == NSEG - 1)
+            B[g] = act[sg] ? B[g] : 0u; // (idle lanes; in the blocked mapping that is every group of the lane)
         worst |= B[g];
     }
-    const bool unsure = active && ((worst & 0xffffu) + (worst >> 16)) > 21u; // 6 * (lo + hi) < 128 <=> lo + hi <= 21
+    const bool unsure = ((worst & 0xffffu) + (worst >> 16)) > 21u; // 6 * (lo + hi) < 128 <=> lo + hi <= 21
     if (!(emit && __builtin_amdgcn_ballot_w64(unsure)))
         return;
     // ---- rare: some group of this row cannot be proven zero -----------------------------------------------
@@ -670,7 +788,7 @@ __device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const int par, const
     uint32_t total = 0;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
-        mine[g] = active && ((B[g] & 0xffffu) + (B[g] >> 16)) > 21u;
+        mine[g] = act[Map::segOf(GS * g)] && ((B[g] & 0xffffu) + (B[g] >> 16)) > 21u;
         bm[g] = __builtin_amdgcn_ballot_w64(mine[g]);
         const int nq = GS * g + GS <= NDW ? GS : NDW - GS * g; // 4-pixel groups of this recurrence group
         total += (uint32_t)nq * (uint32_t)__builtin_popcountll(bm[g]);
@@ -680,18 +798,20 @@ __device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const int par, const
         J.handover = y; // dense rows (or the LDS list is full): the rest of the chunk goes to the row machine
         return;
     }
-    const uint32_t code0 = (uint32_t)y * ngroups + (uint32_t)lane * NDW;
     uint32_t base = J.npend;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         const unsigned long long b = bm[g];
         if (b) {
             const int nq = GS * g + GS <= NDW ? GS : NDW - GS * g;
+            const int sg = Map::segOf(GS * g);
+            // global index of the recurrence group's first 4-pixel group
+            const uint32_t code0 = (uint32_t)y * ngroups + (uint32_t)(map.gbase[sg] + Map::segK(sg) * lane + (GS * g - Map::segD0(sg)));
             const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
             if (mine[g]) {
 #pragma unroll
                 for (int q = 0; q < nq; q++)
-                    pend[base + (uint32_t)nq * below + q] = code0 + GS * g + q;
+                    pend[base + (uint32_t)nq * below + q] = code0 + q;
             }
             base += (uint32_t)nq * (uint32_t)__builtin_popcountll(b);
         }
@@ -825,8 +945,6 @@ __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ 
     const uint8_t *sg = sigma6 + (size_t)jb.model * P;
     const int nl = W / (4 * NDW);
     const bool active = lane < nl;
-    const bool first_lane = lane == 0;
-    const bool last_lane = lane == nl - 1;
     const int xoff = active ? lane * 4 * NDW : 0;
     const int y0 = chunk * rows_per_chunk;
     int y1 = y0 + rows_per_chunk;
@@ -835,6 +953,8 @@ __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ 
     const int T = y1 - y0 + 4; // input rows y0-2 .. y1+1 (reflected); step tt bounds output row y0+tt-4
     const uint32_t ngroups = (uint32_t)W / 4;
 
+    ScanMap<NDW, false> map;
+    map.init(W);
     K2BoundJob<NDW> J;
 #pragma unroll
     for (int g = 0; g < K2BoundJob<NDW>::NG; g++)
@@ -862,7 +982,7 @@ __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ 
 #pragma unroll
                 for (int g = 0; g < NDW; g++)
                     m[g] = (Xp[2 * g] + Xn[2 * g]) + (Xp[2 * g + 1] + Xn[2 * g + 1]);
-                k2b_row<NDW>(J, u, m, tt >= 4 && tt < T, y0 + tt - 4, active, first_lane, last_lane, lane, ngroups, budget, pend);
+                k2b_row<NDW, false>(J, u, m, tt >= 4 && tt < T, y0 + tt - 4, map, lane, ngroups, budget, pend);
                 if (STORE && tt >= 4 && tt < T && J.handover < 0 && active)
                     k2b_store_zero_row<NDW>(dbase + (ptrdiff_t)(y0 + tt - 4) * W);
             }
@@ -887,7 +1007,7 @@ __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ 
 // The chain property is only a hint: the wave checks it on the job records and hands units it cannot chain to the row
 // machine, so any job list gives the same histograms as k2_bound_scan / k2_rows.
 // ------------------------------------------------------------------------------------------------
-template <int NDW, int K, bool STORE>
+template <int NDW, int K, bool STORE, bool SPLIT>
 __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__ frames,
                                                      const uint8_t *__restrict__ sigma6,
                                                      const abub_job *__restrict__ jobs, int L, int S, int nslot, int W,
@@ -942,15 +1062,12 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
     for (int t = 0; t < K; t++)
         fp[t + 1] = frames + (size_t)jb[t].cur * P;
     const uint8_t *sg = sigma6 + (size_t)jb[0].model * P;
-    const int nl = W / (4 * NDW);
-    const bool active = lane < nl;
-    const bool first_lane = lane == 0;
-    const bool last_lane = lane == nl - 1;
-    const int xoff = active ? lane * 4 * NDW : 0;
+    ScanMap<NDW, SPLIT> map;
+    map.init(W);
     uint8_t *dbase[K];
 #pragma unroll
     for (int t = 0; t < K; t++)
-        dbase[t] = STORE ? diff + (size_t)jb[t].out * P + xoff : nullptr;
+        dbase[t] = STORE ? diff + (size_t)jb[t].out * P : nullptr;
     const int T = y1 - y0 + 4;
     const uint32_t ngroups = (uint32_t)W / 4;
 #pragma unroll
@@ -971,14 +1088,9 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
     uint32_t raw[U][K + 2][NDW];
 #define K2C_LOAD(SL, Y)                                                                       \
     {                                                                                         \
-        const size_t o_ = (size_t)(Y) * W + xoff;                                             \
-        _Pragma("unroll") for (int f = 0; f <= K; f++)                                        \
-        {                                                                                     \
-            const uint32_t *pf_ = reinterpret_cast<const uint32_t *>(fp[f] + o_);             \
-            _Pragma("unroll") for (int d = 0; d < NDW; d++) raw[SL][f][d] = pf_[d];           \
-        }                                                                                     \
-        const uint32_t *ps_ = reinterpret_cast<const uint32_t *>(sg + o_);                    \
-        _Pragma("unroll") for (int d = 0; d < NDW; d++) raw[SL][K + 1][d] = ps_[d];           \
+        const size_t o_ = (size_t)(Y) * W;                                                    \
+        _Pragma("unroll") for (int f = 0; f <= K; f++) map.load(raw[SL][f], fp[f] + o_, lane); \
+        map.load(raw[SL][K + 1], sg + o_, lane);                                              \
     }
 #pragma unroll
     for (int q = 0; q < PF; q++) {
@@ -1026,10 +1138,9 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
                     for (int g = 0; g < NDW; g++) // sat(c - (r + s)) + sat(r - (c + s)), both pairs of the group
                         m[g] = (pk_subsat(cw[2 * g], ps[2 * g]) + pk_subsat(pw[2 * g], cs[2 * g])) +
                                (pk_subsat(cw[2 * g + 1], ps[2 * g + 1]) + pk_subsat(pw[2 * g + 1], cs[2 * g + 1]));
-                    k2b_row<NDW>(J[t], u, m, tt >= 4 && tt < T, y0 + tt - 4, active, first_lane, last_lane, lane, ngroups,
-                                 budget, pend[t]);
-                    if (STORE && tt >= 4 && tt < T && J[t].handover < 0 && active)
-                        k2b_store_zero_row<NDW>(dbase[t] + (ptrdiff_t)(y0 + tt - 4) * W);
+                    k2b_row<NDW, SPLIT>(J[t], u, m, tt >= 4 && tt < T, y0 + tt - 4, map, lane, ngroups, budget, pend[t]);
+                    if (STORE && tt >= 4 && tt < T && J[t].handover < 0)
+                        map.store_zero(dbase[t] + (ptrdiff_t)(y0 + tt - 4) * W, lane);
                 }
 #pragma unroll
                 for (int j = 0; j < 2 * NDW; j++) {
@@ -1228,6 +1339,7 @@ struct K2Options {
     int chain = 2;     // jobs per wave in the chained scan (2 or 3; 0 = never chain)
     int budget = 512;  // suspects a chunk may remember (LDS) before it hands its rows over (<= K2B_PEND)
     int pf = 1;        // software-prefetch depth of the row machine in rows (1 or 2)
+    int split = 1;     // chained scan: "split" lane mapping where the row width allows it (0: always blocked)
     bool loaded = false;
 };
 static K2Options g_k2opt;
@@ -1245,6 +1357,8 @@ static K2Options k2_options()
                 g_k2opt.budget = atoi(e);
         if (const char *e = getenv("ABUB_K2_PF"))
             g_k2opt.pf = atoi(e);
+        if (const char *e = getenv("ABUB_K2_SPLIT"))
+            g_k2opt.split = atoi(e);
         g_k2opt.loaded = true;
     }
     return g_k2opt;
@@ -1264,6 +1378,8 @@ extern "C" int abub_k2_set_option(const char *name, int value)
         g_k2opt.budget = value;
     else if (!strcmp(name, "pf"))
         g_k2opt.pf = value;
+    else if (!strcmp(name, "split"))
+        g_k2opt.split = value;
     else
         return set_err(ABUB_E_INVALID, "abub_k2_set_option: unknown option or bad value");
     return ABUB_OK;
@@ -1298,9 +1414,20 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
                 nslot += nr > 0 ? (nr + Kc - 1) / Kc : 0;
             }
             const dim3 grid((unsigned)((size_t)(njobs / L) * nslot * nchunks));
+            // the scan's own lane mapping: whole 16 / 8 / 4-byte pieces per lane ("split") where the row decomposes
+            // that way (W = 1280, 1680, ...), the row machine's blocked mapping otherwise
+            // (measured, A/B on one box: store mode -13 % at W = 1280 and -4 % at 1680 -- the zero rows go out as whole
+            // lines --; trigger-only equal at 1280 and 2-7 % slower at 1680, where the three segments cost more
+            // neighbour-exchange instructions than the loads gain: split there only when D is stored)
+            constexpr bool CAN_SPLIT = NDW >= 5 && NDW <= 7;
+            const bool split = CAN_SPLIT && opt.split && split_ndw(W) == NDW && (diff != nullptr || NDW == 5 || opt.split > 1);
 #define K2C_LAUNCH(KK, ST)                                                                                          \
-    hipLaunchKernelGGL((k2_bound_chain<NDW, KK, ST>), grid, dim3(64), 0, st, frames, sigma6, jobs, L, S, nslot, W,  \
-                       H, R, nchunks, budget, units, counters, hist, diff)
+    if (split)                                                                                                      \
+        hipLaunchKernelGGL((k2_bound_chain<NDW, KK, ST, CAN_SPLIT>), grid, dim3(64), 0, st, frames, sigma6, jobs, L, \
+                           S, nslot, W, H, R, nchunks, budget, units, counters, hist, diff);                        \
+    else                                                                                                            \
+        hipLaunchKernelGGL((k2_bound_chain<NDW, KK, ST, false>), grid, dim3(64), 0, st, frames, sigma6, jobs, L, S, \
+                           nslot, W, H, R, nchunks, budget, units, counters, hist, diff)
             if (Kc == 3) {
                 if (diff) {
                     K2C_LAUNCH(3, true);

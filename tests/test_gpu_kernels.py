@@ -18,6 +18,7 @@ def _k2_defaults():
     hip.k2_set_option("bound", 1)
     hip.k2_set_option("chain", 2)
     hip.k2_set_option("budget", 1024)
+    hip.k2_set_option("split", 1)
 
 
 def rnd_frames(rs, n, H, W, base=None, amp=12):
@@ -333,7 +334,8 @@ def test_k2_trigger_only_equals_store_mode_full_size(W, H):
     assert int(h_store[19, 1:].sum()) > W * H // 2  # the dense frame really is dense
 
 
-@pytest.mark.parametrize("W,H,F,off", [(1280, 64, 12, 2), (1680, 40, 9, 2), (256, 48, 7, 1), (1280, 33, 6, 3), (512, 40, 5, 2)])
+@pytest.mark.parametrize("W,H,F,off", [(1280, 64, 12, 2), (1680, 40, 9, 2), (256, 48, 7, 1), (1280, 33, 6, 3), (512, 40, 5, 2),
+                                       (1540, 24, 6, 2), (1400, 24, 6, 2), (1100, 24, 6, 2), (1792, 20, 5, 2), (1028, 20, 5, 1)])
 def test_k2_chained_trigger_pass(oracle, W, H, F, off):
     """abub_diff_hist_chained_dev: the stack-structured job list (job i refs the cur frame of job i - off) scanned with
     shared row loads must give the histograms of the plain entry and of the oracle; a WRONG hint (stride or length that
@@ -360,16 +362,19 @@ def test_k2_chained_trigger_pass(oracle, W, H, F, off):
     _, href = oracle_hists(oracle, frames, sigma, [tuple(r) for r in jn])
     assert np.array_equal(plain.cpu().numpy().astype(np.uint32), href)
     Dref, _ = oracle_hists(oracle, frames, sigma, [tuple(r) for r in jn])
-    for K in (2, 3):
+    # chain = jobs per wave; split = the scan's lane mapping (whole 16/8/4-byte pieces per lane where the width allows
+    # it -- 1280 {4,1}, 1400 {4,2}, 1540 / 1680 / 1792 {4,2,1}, 1100 {4,1} with a partial last segment -- or blocked)
+    for K, split in ((2, 1), (3, 1), (2, 0)):
         hip.k2_set_option("chain", K)
+        hip.k2_set_option("split", split)
         for L, S in [(F - 1, off), (F - 1, off + 1), (F - 1, 1), ((F - 1) * nst, off), (1, 1)]:
             if ((F - 1) * nst) % L:
                 continue
             got, _ = hip.diff_hist(f_d, s6, jobs, W, H, chain=(L, S))
-            assert torch.equal(got, plain), (K, L, S)
+            assert torch.equal(got, plain), (K, split, L, S)
             got, D = hip.diff_hist(f_d, s6, jobs, W, H, chain=(L, S), store=True)
-            assert torch.equal(got, plain), (K, L, S)
-            assert np.array_equal(D.cpu().numpy(), Dref), (K, L, S)
+            assert torch.equal(got, plain), (K, split, L, S)
+            assert np.array_equal(D.cpu().numpy(), Dref), (K, split, L, S)
 
 
 def test_scratch_release_and_reuse():
