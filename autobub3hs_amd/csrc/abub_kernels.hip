@@ -1336,7 +1336,8 @@ static void launch_k2_rows_pf(const uint8_t *frames, const uint8_t *sigma6, cons
 // the bound-and-verify pass and the plain row machine inside one process).
 struct K2Options {
     int bound = 1;     // 0: always the full row machine (k2_rows); 1: bound-and-verify (trigger-only AND store mode)
-    int chain = 2;     // jobs per wave in the chained scan (2 or 3; 0 = never chain)
+    int chain = -1;    // jobs per wave in the chained scan: 2 or 3; 0 = never chain; -1 = automatic (3 for rows of up to
+                       // 5 dwords per lane -- measured 3 % faster at W = 1280 --, 2 for wider rows: registers)
     int budget = 512;  // suspects a chunk may remember (LDS) before it hands its rows over (<= K2B_PEND)
     int pf = 1;        // software-prefetch depth of the row machine in rows (1 or 2)
     int split = 1;     // chained scan: "split" lane mapping where the row width allows it (0: always blocked)
@@ -1406,8 +1407,9 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
         uint2 *units = (uint2 *)(scr + 256);
         HIPCHK(hipMemsetAsync(counters, 0, sizeof(uint32_t), st));
         const int L = ca.chain_len, S = ca.chain_stride;
-        if (opt.chain >= 2 && L > 0 && S > 0 && S <= 8 && njobs % L == 0 && !ca.cthr) {
-            const int Kc = opt.chain >= 3 ? 3 : 2;
+        const int chainK = opt.chain < 0 ? (NDW <= 5 ? 3 : 2) : opt.chain;
+        if (chainK >= 2 && L > 0 && S > 0 && S <= 8 && njobs % L == 0 && !ca.cthr) {
+            const int Kc = chainK >= 3 ? 3 : 2;
             int nslot = 0;
             for (int r = 0; r < S; r++) {
                 const int nr = (L - r + S - 1) / S;

@@ -127,7 +127,8 @@ int abub_diff_hist_chained_store_dev(const uint8_t *frames, const uint8_t *sigma
 
 /* Run-time tuning knobs of the K2 launchers (defaults from ABUB_K2_BOUND / _CHAIN / _BUDGET / _PF in the environment):
  *   "bound"  1 = bound-and-verify pass (default), 0 = the plain row machine for every row (the dense-regime worst case)
- *   "chain"  jobs per wave of the chained scan: 2 (default) or 3; 0 = never chain
+ *   "chain"  jobs per wave of the chained scan: 2 or 3; 0 = never chain; -1 (default) = 3 for W <= 1280, else 2
+ *   "split"  1 (default) = the chained scan's whole-piece lane mapping where it pays, 0 = never, 2 = wherever possible
  *   "budget" suspects a chunk may list before it hands its remaining rows to the row machine
  *   "pf"     software-prefetch depth of the row machine (1 or 2)
  * Results never depend on them. */

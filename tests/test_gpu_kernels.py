@@ -16,7 +16,7 @@ def _k2_defaults():
     """Every test starts from (and leaves behind) the default K2 launcher options."""
     yield
     hip.k2_set_option("bound", 1)
-    hip.k2_set_option("chain", 2)
+    hip.k2_set_option("chain", -1)
     hip.k2_set_option("budget", 1024)
     hip.k2_set_option("split", 1)
 
@@ -364,7 +364,7 @@ def test_k2_chained_trigger_pass(oracle, W, H, F, off):
     Dref, _ = oracle_hists(oracle, frames, sigma, [tuple(r) for r in jn])
     # chain = jobs per wave; split = the scan's lane mapping (whole 16/8/4-byte pieces per lane where the width allows
     # it -- 1280 {4,1}, 1400 {4,2}, 1540 / 1680 / 1792 {4,2,1}, 1100 {4,1} with a partial last segment -- or blocked)
-    for K, split in ((2, 1), (3, 1), (2, 0)):
+    for K, split in ((2, 2), (3, 2), (2, 0), (-1, 1)):
         hip.k2_set_option("chain", K)
         hip.k2_set_option("split", split)
         for L, S in [(F - 1, off), (F - 1, off + 1), (F - 1, 1), ((F - 1) * nst, off), (1, 1)]:
