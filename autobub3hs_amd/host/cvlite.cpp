@@ -9,12 +9,69 @@
 #ifndef ABUB_USE_OPENCV
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
+#include <dlfcn.h>
 #include <zlib.h>
 
 namespace cv {
+
+// Optional fast path for the inflate of PNG / zip payloads: libdeflate (2-3x zlib's speed), when the system has the
+// shared library (no headers needed: three functions of its stable C ABI, looked up at run time).  Absent -> zlib.
+namespace {
+struct LibDeflate {
+    void *(*alloc)() = nullptr;
+    int (*zlibDecompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    void (*freeD)(void *) = nullptr;
+    LibDeflate()
+    {
+        const char *off = getenv("ABUB_NO_LIBDEFLATE");
+        if (off && atoi(off))
+            return;
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h)
+            return;
+        alloc = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
+        zlibDecompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_zlib_decompress");
+        freeD = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        if (!alloc || !zlibDecompress || !freeD)
+            alloc = nullptr;
+    }
+};
+const LibDeflate &libDeflate()
+{
+    static LibDeflate l;
+    return l;
+}
+struct ThreadDecompressor {
+    void *d = nullptr;
+    ~ThreadDecompressor()
+    {
+        if (d)
+            libDeflate().freeD(d);
+    }
+};
+// zlib-wrapped deflate stream -> exactly `outLen` bytes; false on any error
+bool inflateZlibStream(const uchar *in, size_t inLen, uchar *out, size_t outLen)
+{
+    const LibDeflate &l = libDeflate();
+    if (l.alloc) {
+        static thread_local ThreadDecompressor td;
+        if (!td.d)
+            td.d = l.alloc();
+        if (td.d) {
+            size_t got = 0;
+            if (l.zlibDecompress(td.d, in, inLen, out, outLen, &got) == 0 && got == outLen)
+                return true;
+            // (fall through: let zlib have a look, e.g. trailing data libdeflate refuses)
+        }
+    }
+    uLongf rawLen = (uLongf)outLen;
+    return uncompress(out, &rawLen, in, (uLong)inLen) == Z_OK && rawLen == outLen;
+}
+} // namespace
 
 static inline uchar bgr2grey(int b, int g, int r) { return (uchar)((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14); }
 static inline uchar png_rgb2grey(int r, int g, int b) { return (uchar)((r * 9797 + g * 19234 + b * 3737 + 16384) >> 15); }
@@ -146,27 +203,71 @@ static Mat decodePNG(const uchar *buf, size_t size)
     const size_t rowBytes = ((size_t)w * bitsPerPixel + 7) / 8;
     const size_t bpp = bitsPerPixel >= 8 ? bitsPerPixel / 8 : 1; // filter distance
     std::vector<uchar> raw((rowBytes + 1) * (size_t)h);
-    uLongf rawLen = (uLongf)raw.size();
-    if (uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size()) != Z_OK || rawLen != raw.size())
+    if (!inflateZlibStream(idat.data(), idat.size(), raw.data(), raw.size()))
         return out;
     out.create((int)h, (int)w, CV_8U);
+    // grey / palette lookup tables (the frames of a run are 8-bit grey or 8-bit palettised: one table look-up per pixel)
+    uchar lut[256];
+    for (int v = 0; v < 256; ++v)
+        lut[v] = ctype == 3 ? (v < npal ? png_rgb2grey(pal[v][0], pal[v][1], pal[v][2]) : 0) : (uchar)v;
+    const bool direct8 = ctype == 0 && depth == 8; // rows can be unfiltered straight into the output image
     std::vector<uchar> prev(rowBytes, 0), cur(rowBytes);
+    std::vector<uchar> zero(rowBytes, 0);
     for (unsigned y = 0; y < h; ++y) {
         const uchar *src = raw.data() + (rowBytes + 1) * (size_t)y;
         const int ft = src[0];
         ++src;
-        for (size_t i = 0; i < rowBytes; ++i) {
-            const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
-            int v = src[i];
-            switch (ft) {
-            case 0: break;
-            case 1: v += a; break;
-            case 2: v += b; break;
-            case 3: v += (a + b) >> 1; break;
-            case 4: v += paeth(a, b, c); break;
-            default: out.release(); return out;
+        // the filter type is constant along a row: one tight loop per type (the row above is `up`, zeros for row 0)
+        uchar *rowOut = direct8 ? out.ptr<uchar>((int)y) : cur.data();
+        const uchar *up = y == 0 ? zero.data() : (direct8 ? out.ptr<uchar>((int)y - 1) : prev.data());
+        switch (ft) {
+        case 0:
+            std::memcpy(rowOut, src, rowBytes);
+            break;
+        case 1:
+            for (size_t i = 0; i < bpp && i < rowBytes; ++i)
+                rowOut[i] = src[i];
+            for (size_t i = bpp; i < rowBytes; ++i)
+                rowOut[i] = (uchar)(src[i] + rowOut[i - bpp]);
+            break;
+        case 2:
+            for (size_t i = 0; i < rowBytes; ++i)
+                rowOut[i] = (uchar)(src[i] + up[i]);
+            break;
+        case 3:
+            for (size_t i = 0; i < bpp && i < rowBytes; ++i)
+                rowOut[i] = (uchar)(src[i] + (up[i] >> 1));
+            for (size_t i = bpp; i < rowBytes; ++i)
+                rowOut[i] = (uchar)(src[i] + ((rowOut[i - bpp] + up[i]) >> 1));
+            break;
+        case 4:
+            for (size_t i = 0; i < bpp && i < rowBytes; ++i)
+                rowOut[i] = (uchar)(src[i] + up[i]); // paeth(0, b, 0) = b
+            if (bpp == 1) { // the common case, with a and c carried in registers
+                int a = rowBytes ? rowOut[0] : 0, c = rowBytes ? up[0] : 0;
+                for (size_t i = 1; i < rowBytes; ++i) {
+                    const int b = up[i];
+                    a = (uchar)(src[i] + paeth(a, b, c));
+                    rowOut[i] = (uchar)a;
+                    c = b;
+                }
+            } else {
+                for (size_t i = bpp; i < rowBytes; ++i)
+                    rowOut[i] = (uchar)(src[i] + paeth(rowOut[i - bpp], up[i], up[i - bpp]));
             }
-            cur[i] = (uchar)v;
+            break;
+        default:
+            out.release();
+            return out;
+        }
+        if (direct8)
+            continue;
+        if ((ctype == 0 || ctype == 3) && depth == 8) { // 8-bit palette (or grey through the identity table)
+            uchar *d8 = out.ptr<uchar>((int)y);
+            for (unsigned x = 0; x < w; ++x)
+                d8[x] = lut[cur[x]];
+            prev.swap(cur);
+            continue;
         }
         uchar *dst = out.ptr<uchar>((int)y);
         for (unsigned x = 0; x < w; ++x) {

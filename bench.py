@@ -55,7 +55,7 @@ def parse(argv=None):
     ap.add_argument("--max-blocks", type=int, default=400)
     ap.add_argument("--micro-frames", type=int, default=10000,
                     help="frames of the configs[2] kernel microbench slab (0 = skip)")
-    ap.add_argument("--ingest-events", type=int, default=12,
+    ap.add_argument("--ingest-events", type=int, default=24,
                     help="events of the run written as a PNG zip archive on local disk and detected from there through the "
                          "batched ingestion path (decode-inclusive rate, config.ingest_inclusive; 0 = skip)")
     ap.add_argument("--latency-steps", type=int, default=5, help="steps run one at a time for the latency figure (0 = skip)")
