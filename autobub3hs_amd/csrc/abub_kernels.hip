@@ -592,44 +592,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER
 #define K2B_SUB 32 /* rows per handed-over piece */
 #endif
 
-// Lane -> pixel mapping of the scan kernels.  A row is cut into segments; in segment s every lane owns segK(s)
+// Lane -> pixel mapping of the scan kernels.  A row is cut into segments; in segment s every active lane owns segK(s)
 // consecutive dwords (4-pixel groups): lane L the groups [gbase[s] + segK(s) * L, + segK(s)).
 //   blocked (SPLIT = false): one segment of NDW dwords per lane -- the row machine's mapping; a lane's dwordx4 + dword
 //                            loads then sit at a 4 * NDW byte stride, so every load instruction touches every line
 //                            of the row partially;
-//   split   (SPLIT = true):  NDW = 5 -> {4,1}, 6 -> {4,2}, 7 -> {4,2,1} dwords: each load instruction (dwordx4, dwordx2,
-//                            dword) covers ONE contiguous span of the row with whole 16 / 8 / 4-byte pieces per lane.
-//                            tools/rowload_bench.cpp: the chained scan's access pattern is 3 % cheaper at W = 1280 and
-//                            12 % at W = 1680 this way.  Only the last segment may have idle lanes.
+//   split   (SPLIT = true):  two segments of 4 and NDW - 4 dwords per lane (NDW = 5 .. 7) over the same nl = W / (4 NDW)
+//                            lanes: the first 16 * nl bytes of the row go out as one dwordx4 per lane, the rest as one
+//                            dword / dwordx2 / dwordx3 per lane -- each load instruction covers ONE contiguous span of
+//                            the row with whole pieces per lane.  tools/rowload_bench.cpp: the chained scan's access
+//                            pattern is 3 % cheaper at W = 1280 and 12 % at W = 1680 this way.
 // The suspect codes are global group indices and hand-overs are row ranges, so the row machine (always blocked) and
 // the exact tails do not care which mapping the scan used.
 template <int NDW, bool SPLIT>
 struct ScanMap {
-    static constexpr int NSEG = !SPLIT ? 1 : (NDW == 7 ? 3 : 2);
-    static __device__ __host__ constexpr int segK(int s) { return !SPLIT ? NDW : (s == 0 ? 4 : (NDW == 5 ? 1 : (NDW == 6 ? 2 : (s == 1 ? 2 : 1)))); }
-    static __device__ __host__ constexpr int segD0(int s) { return !SPLIT ? 0 : (s == 0 ? 0 : (s == 1 ? 4 : 6)); }
-    static __device__ __host__ constexpr int segOf(int d) { return !SPLIT ? 0 : (d < 4 ? 0 : (d < 6 && NDW != 5 ? 1 : NSEG - 1)); }
-    int n[NSEG];     // active lanes of the segment
-    int gbase[NSEG]; // its first 4-pixel group
+    static_assert(!SPLIT || (NDW >= 5 && NDW <= 7), "the split mapping is a dwordx4 plus 1 .. 3 dwords per lane");
+    static constexpr int NSEG = SPLIT ? 2 : 1;
+    static __device__ __host__ constexpr int segK(int s) { return !SPLIT ? NDW : (s == 0 ? 4 : NDW - 4); }
+    static __device__ __host__ constexpr int segD0(int s) { return !SPLIT ? 0 : (s == 0 ? 0 : 4); }
+    static __device__ __host__ constexpr int segOf(int d) { return !SPLIT ? 0 : (d < 4 ? 0 : 1); }
+    int nl;          // active lanes (the same in every segment)
+    int gbase[NSEG]; // first 4-pixel group of the segment
     __device__ __forceinline__ void init(int W)
     {
-        const int ng = W / 4;
-        if (!SPLIT) {
-            n[0] = ng / NDW;
-            gbase[0] = 0;
-        } else {
-            int g = 0;
+        nl = W / (4 * NDW);
 #pragma unroll
-            for (int s = 0; s < NSEG; s++) {
-                gbase[s] = g;
-                const int left = (ng - g) / segK(s);
-                n[s] = left < 64 ? left : 64;
-                g += 64 * segK(s);
-            }
-        }
+        for (int s = 0; s < NSEG; s++)
+            gbase[s] = nl * segD0(s);
     }
     // byte offset of the lane's piece of segment s in a row (idle lanes shadow lane 0: valid address, results unused)
-    __device__ __forceinline__ int byteoff(int s, int lane) const { return 4 * (gbase[s] + segK(s) * (lane < n[s] ? lane : 0)); }
+    __device__ __forceinline__ int byteoff(int s, int lane) const { return 4 * (gbase[s] + segK(s) * (lane < nl ? lane : 0)); }
     __device__ __forceinline__ void load(uint32_t (&r)[NDW], const uint8_t *__restrict__ row, int lane) const
     {
 #pragma unroll
@@ -642,30 +634,17 @@ struct ScanMap {
     }
     __device__ __forceinline__ void store_zero(uint8_t *__restrict__ row, int lane) const
     {
+        if (lane < nl) {
 #pragma unroll
-        for (int s = 0; s < NSEG; s++)
-            if (lane < n[s]) {
+            for (int s = 0; s < NSEG; s++) {
                 uint32_t *p = reinterpret_cast<uint32_t *>(row + byteoff(s, lane));
 #pragma unroll
                 for (int d = 0; d < segK(s); d++)
                     p[d] = 0;
             }
+        }
     }
 };
-// the split decomposition exists for 256 < W / 4 <= 448 groups: returns the NDW of the segment set, or 0
-static int split_ndw(int W)
-{
-    if (W <= 0 || (W & 3))
-        return 0;
-    const int ng = W / 4;
-    if (ng > 256 && ng <= 320)
-        return 5;
-    if (ng > 320 && ng <= 384 && ((ng - 256) & 1) == 0)
-        return 6;
-    if (ng > 384 && ng <= 448)
-        return 7;
-    return 0;
-}
 
 template <int NDW>
 struct K2BoundJob { // per-job state of the bound recurrence and of its suspect list (all wave-uniform but b*/Mprev)
@@ -704,32 +683,72 @@ __device__ __forceinline__ void k2b_hand_over(uint2 *__restrict__ units, uint32_
     }
 }
 
+// ---- the launch's global suspect list (K2 and K3 scans) -----------------------------------------------------------
+// The scanning waves only MOVE their LDS suspect lists to a global list {job, group code}; sus_tail_list evaluates it
+// afterwards with the whole chip (see there for why).  SusList.list == nullptr: no global list, the waves evaluate
+// their suspects themselves.
+struct SusList {
+    uint2 *list;
+    uint32_t *count;
+    uint32_t cap;
+};
+#define SUSL_UB 4 /* entries per lane and block iteration of sus_tail_list, at most */
+template <int KIND, bool COMPACT, bool STORE>
+__global__ __launch_bounds__(256) void sus_tail_list(const uint8_t *__restrict__ frames, const uint8_t *__restrict__ mu,
+                              const uint8_t *__restrict__ sigma6, const abub_job *__restrict__ jobs, int W, int H,
+                              uint32_t *__restrict__ hist, uint8_t *__restrict__ img, const uint2 *__restrict__ glist,
+                              const uint32_t *__restrict__ gcount, uint32_t gcap, const int32_t *__restrict__ cthr,
+                              uint32_t *pairs, uint32_t pcap, uint32_t *pcount, uint32_t slot_base);
+// moves `n` codes of one job to the global list at `base` (reserved by the caller); slots beyond the capacity are dropped
+__device__ __forceinline__ void sus_copy_out(const uint32_t *pend, uint32_t n, uint32_t job, uint2 *__restrict__ glist, uint32_t base,
+                                             int lane)
+{
+    for (uint32_t i = lane; i < n; i += 64)
+        glist[base + i] = make_uint2(job, pend[i]);
+}
+// reserves n entries; false (and the slots it did get are marked empty) when the list cannot take them
+__device__ __forceinline__ bool sus_reserve(uint32_t n, uint2 *__restrict__ glist, uint32_t *__restrict__ gcount, uint32_t gcap,
+                                            uint32_t &base, int lane)
+{
+    if (!glist)
+        return false;
+    uint32_t b = 0;
+    if (lane == 0)
+        b = atomicAdd(gcount, n);
+    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+    base = b;
+    if (b < gcap && gcap - b >= n)
+        return true;
+    for (uint32_t i = b + lane; i < gcap && i - b < n; i += 64) // (b may already lie beyond the capacity)
+        glist[i] = make_uint2(0xffffffffu, 0u);
+    return false;
+}
+
+// wave-level ordering of LDS traffic (a list belongs to one wave; LDS executes a wave's instructions in order)
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // one input row of one job: group masses m[] -> bound of output row y; suspects go to the job's LDS list.
 // Everything that steers control flow is read through SGPRs (ballots, s_bcnt1), so the scan loops compile to scalar
 // branches.
 template <int NDW, bool SPLIT>
 __device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const int par, uint32_t (&m)[NDW], bool emit, int y,
                                         const ScanMap<NDW, SPLIT> &map, int lane, uint32_t ngroups, uint32_t budget,
-                                        uint32_t *pend)
+                                        uint32_t *pend, const SusList &gl)
 {
     using Map = ScanMap<NDW, SPLIT>;
     constexpr int NSEG = Map::NSEG;
     // masses of the groups left of each segment's first and right of its last group: neighbour lanes inside a
-    // segment (DPP), the adjacent segment's end at lane 0 / the last lane (one v_readlane), the replicated own edge
-    // group at the image border (the reflected column lies inside it)
-    bool act[NSEG];
+    // segment (DPP), the adjacent segment's end at lane 0 / the last active lane (one v_readlane), the replicated own
+    // edge group at the image border (the reflected column lies inside it).  Idle lanes (lane >= nl) carry lane 0's
+    // pixels: nothing reads their masses (the last active lane takes its right neighbour from the edge value) and
+    // their bounds are masked out of the row test below.
+    const bool act = lane < map.nl;
+    const int lastLane = map.nl - 1;
     uint32_t mLs[NSEG], mRs[NSEG];
-#pragma unroll
-    for (int s = 0; s < NSEG; s++) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        act[s] = lane < map.n[s];
-    }
-    if (SPLIT) { // idle lanes of the (partial) last segment carry lane 0's pixels: their masses must not count
-#pragma unroll
-        for (int d = Map::segD0(NSEG - 1); d < NDW; d++)
-            m[d] = act[NSEG - 1] ? m[d] : 0u;
-    }
 #pragma unroll
     for (int s = 0; s < NSEG; s++) {
         const int dF = Map::segD0(s), dL = Map::segD0(s) + Map::segK(s) - 1;
@@ -737,11 +756,11 @@ __device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const int par, uint3
         uint32_t r = __builtin_amdgcn_update_dpp(0u, m[dF], DPP_WAVE_SHL1, 0xf, 0xf, false);
         uint32_t edgeL = m[dF], edgeR = m[dL];
         if (s > 0)
-            edgeL = __builtin_amdgcn_readlane(m[Map::segD0(s - 1) + Map::segK(s - 1) - 1], 63); // (inner segments are full)
+            edgeL = __builtin_amdgcn_readlane(m[Map::segD0(s - 1) + Map::segK(s - 1) - 1], lastLane);
         if (s + 1 < NSEG)
             edgeR = __builtin_amdgcn_readlane(m[Map::segD0(s + 1)], 0);
         mLs[s] = lane == 0 ? edgeL : l;
-        mRs[s] = lane == map.n[s] - 1 ? edgeR : r;
+        mRs[s] = lane == lastLane ? edgeR : r;
     }
     constexpr int NG = K2BoundJob<NDW>::NG;
     constexpr int GS = K2BoundJob<NDW>::GS;
@@ -775,11 +794,9 @@ __device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const int par, uint3
             J.P[2][0][g] = J.P[3][0][g] + M4;
             J.P[3][0][g] = M;
         }
-        if (sg == NSEG - 1)
-            B[g] = act[sg] ? B[g] : 0u; // (idle lanes; in the blocked mapping that is every group of the lane)
         worst |= B[g];
     }
-    const bool unsure = ((worst & 0xffffu) + (worst >> 16)) > 21u; // 6 * (lo + hi) < 128 <=> lo + hi <= 21
+    const bool unsure = act && ((worst & 0xffffu) + (worst >> 16)) > 21u; // 6 * (lo + hi) < 128 <=> lo + hi <= 21
     if (!(emit && __builtin_amdgcn_ballot_w64(unsure)))
         return;
     // ---- rare: some group of this row cannot be proven zero -----------------------------------------------
@@ -788,12 +805,15 @@ __device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const int par, uint3
     uint32_t total = 0;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
-        mine[g] = act[Map::segOf(GS * g)] && ((B[g] & 0xffffu) + (B[g] >> 16)) > 21u;
+        mine[g] = act && ((B[g] & 0xffffu) + (B[g] >> 16)) > 21u;
         bm[g] = __builtin_amdgcn_ballot_w64(mine[g]);
         const int nq = GS * g + GS <= NDW ? GS : NDW - GS * g; // 4-pixel groups of this recurrence group
         total += (uint32_t)nq * (uint32_t)__builtin_popcountll(bm[g]);
     }
     J.hot += total > 32u; // one row of the row machine costs about as much as 30 exact groups
+    // (A full LDS list means a chunk with a lot of structure: for K2 the row machine is the cheaper way through such
+    // rows -- an exact group costs 45 window loads and two 5x5 sums --, so the list is NOT flushed to the global suspect
+    // list to make room, as K3 does; measured: flushing made the tail kernel 2.4x longer than the pieces it saved.)
     if (J.hot >= 4u || J.npend + total > budget) {
         J.handover = y; // dense rows (or the LDS list is full): the rest of the chunk goes to the row machine
         return;
@@ -831,8 +851,63 @@ __device__ __forceinline__ void k2b_store_zero_row(uint8_t *__restrict__ row)
         po[d] = 0;
 }
 
-// The wave's tail: D for the four pixels of every remembered group, straight from the definition
-// (AnalyzerUnit.cpp:351-370), one lane per group; histogram by global atomics (rare), optional store / candidates.
+// D for the four pixels of 4-pixel group `code` (= y * W/4 + x0/4) of a job, straight from the definition
+// (AnalyzerUnit.cpp:351-370): returns the values packed one per byte.  Interior groups read their 12-byte window as
+// three aligned dwords per array and row; the two edge groups (reflected columns) take the byte path.
+__device__ __forceinline__ uint32_t k2_exact_group(const uint8_t *__restrict__ cur, const uint8_t *__restrict__ ref,
+                                                   const uint8_t *__restrict__ sg, int y, int x0, int W, int H)
+{
+    const bool interior = x0 >= 4 && x0 + 8 <= W;
+    int xs[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        xs[j] = reflect101(x0 - 2 + j, W);
+    int Sp[4] = {0, 0, 0, 0}, Sn[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const size_t ro = (size_t)reflect101(y - 2 + i, H) * W;
+        int pp[8], nn[8];
+        if (interior) {
+            const uint32_t *pc = reinterpret_cast<const uint32_t *>(cur + ro + x0 - 4);
+            const uint32_t *pr = reinterpret_cast<const uint32_t *>(ref + ro + x0 - 4);
+            const uint32_t *ps = reinterpret_cast<const uint32_t *>(sg + ro + x0 - 4);
+            const uint32_t cw[3] = {pc[0], pc[1], pc[2]}, rw[3] = {pr[0], pr[1], pr[2]}, sw[3] = {ps[0], ps[1], ps[2]};
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int q = (2 + j) >> 2, sh = 8 * ((2 + j) & 3);
+                const int c = (cw[q] >> sh) & 0xff, r = (rw[q] >> sh) & 0xff, s6 = (sw[q] >> sh) & 0xff;
+                int a = c - r - s6, b = r - c - s6;
+                pp[j] = a > 0 ? a : 0;
+                nn[j] = b > 0 ? b : 0;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int c = cur[ro + xs[j]], r = ref[ro + xs[j]], s6 = sg[ro + xs[j]];
+                int a = c - r - s6, b = r - c - s6;
+                pp[j] = a > 0 ? a : 0;
+                nn[j] = b > 0 ? b : 0;
+            }
+        }
+        const int wv = (i == 0 || i == 4) ? 1 : (i == 2 ? 6 : 4);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            Sp[k] += wv * (pp[k] + 4 * pp[k + 1] + 6 * pp[k + 2] + 4 * pp[k + 3] + pp[k + 4]);
+            Sn[k] += wv * (nn[k] + 4 * nn[k + 1] + 6 * nn[k + 2] + 4 * nn[k + 3] + nn[k + 4]);
+        }
+    }
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int a = (Sp[k] + 128) >> 8, b = (Sn[k] + 128) >> 8;
+        const int d = a > b ? a - b : b - a;
+        packed |= (uint32_t)d << (8 * k);
+    }
+    return packed;
+}
+
+// The wave's own tail (no global list, or it is full): D for the four pixels of every remembered group, one lane per
+// group; histogram by global atomics (rare), optional store / candidates.
 template <bool COMPACT, bool STORE>
 __device__ __forceinline__ void k2b_tail(const uint32_t *pend, uint32_t npend, const abub_job jb, const uint8_t *__restrict__ frames,
                                          const uint8_t *__restrict__ sigma6, int W, int H, uint32_t *__restrict__ hist,
@@ -840,7 +915,7 @@ __device__ __forceinline__ void k2b_tail(const uint32_t *pend, uint32_t npend, c
 {
     if (npend == 0)
         return;
-    __syncthreads(); // (one wave: orders the LDS writes of the scan before the reads below)
+    wave_lds_fence(); // orders the scan's LDS writes before the reads below
     const size_t P = (size_t)W * H;
     const uint32_t ngroups = (uint32_t)W / 4;
     const uint8_t *cur = frames + (size_t)jb.cur * P;
@@ -850,74 +925,30 @@ __device__ __forceinline__ void k2b_tail(const uint32_t *pend, uint32_t npend, c
     const uint32_t nloop = COMPACT ? (npend + 63u) & ~63u : npend;
 #pragma unroll 1
     for (uint32_t e = lane; e < nloop; e += 64) {
-        uint32_t Dv[4] = {0, 0, 0, 0};
-        uint32_t pix0 = 0;
+        uint32_t packed = 0, pix0 = 0;
         if (e < npend) {
             const uint32_t code = pend[e];
             const int y = (int)(code / ngroups), x0 = (int)(code % ngroups) * 4;
-            // interior groups read their 12-byte window as three aligned dwords per array and row; the two edge groups
-            // (reflected columns) take the byte path
-            const bool interior = x0 >= 4 && x0 + 8 <= W;
-            int xs[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                xs[j] = reflect101(x0 - 2 + j, W);
-            int Sp[4] = {0, 0, 0, 0}, Sn[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int i = 0; i < 5; i++) {
-                const size_t ro = (size_t)reflect101(y - 2 + i, H) * W;
-                int pp[8], nn[8];
-                if (interior) {
-                    const uint32_t *pc = reinterpret_cast<const uint32_t *>(cur + ro + x0 - 4);
-                    const uint32_t *pr = reinterpret_cast<const uint32_t *>(ref + ro + x0 - 4);
-                    const uint32_t *ps = reinterpret_cast<const uint32_t *>(sg + ro + x0 - 4);
-                    const uint32_t cw[3] = {pc[0], pc[1], pc[2]}, rw[3] = {pr[0], pr[1], pr[2]}, sw[3] = {ps[0], ps[1], ps[2]};
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const int q = (2 + j) >> 2, sh = 8 * ((2 + j) & 3);
-                        const int c = (cw[q] >> sh) & 0xff, r = (rw[q] >> sh) & 0xff, s6 = (sw[q] >> sh) & 0xff;
-                        int a = c - r - s6, b = r - c - s6;
-                        pp[j] = a > 0 ? a : 0;
-                        nn[j] = b > 0 ? b : 0;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const int c = cur[ro + xs[j]], r = ref[ro + xs[j]], s6 = sg[ro + xs[j]];
-                        int a = c - r - s6, b = r - c - s6;
-                        pp[j] = a > 0 ? a : 0;
-                        nn[j] = b > 0 ? b : 0;
-                    }
-                }
-                const int wv = (i == 0 || i == 4) ? 1 : (i == 2 ? 6 : 4);
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    Sp[k] += wv * (pp[k] + 4 * pp[k + 1] + 6 * pp[k + 2] + 4 * pp[k + 3] + pp[k + 4]);
-                    Sn[k] += wv * (nn[k] + 4 * nn[k + 1] + 6 * nn[k + 2] + 4 * nn[k + 3] + nn[k + 4]);
-                }
-            }
+            packed = k2_exact_group(cur, ref, sg, y, x0, W, H);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int a = (Sp[k] + 128) >> 8, b = (Sn[k] + 128) >> 8;
-                const int d = a > b ? a - b : b - a;
-                Dv[k] = (uint32_t)d;
+                const uint32_t d = (packed >> (8 * k)) & 0xffu;
                 if (d)
                     atomicAdd(&hist[(size_t)jb.out * 256 + d], 1u);
             }
             if (STORE) // (the scan wrote this row as zeros; x0 is a multiple of 4 and W % 4 == 0: an aligned dword)
-                *reinterpret_cast<uint32_t *>(diff + (size_t)jb.out * P + (size_t)y * W + x0) =
-                    Dv[0] | (Dv[1] << 8) | (Dv[2] << 16) | (Dv[3] << 24);
+                *reinterpret_cast<uint32_t *>(diff + (size_t)jb.out * P + (size_t)y * W + x0) = packed;
             pix0 = (uint32_t)(y * W + x0);
         }
         if (COMPACT) { // candidates (value > cut) of the wave's groups: one reservation per wave
             uint32_t c = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                c += (int)Dv[k] > cp.thr;
+                c += (int)((packed >> (8 * k)) & 0xffu) > cp.thr;
             uint32_t pos = compact_reserve(cp, c);
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                compact_put(cp, pos, Dv[k], pix0 + k);
+                compact_put(cp, pos, (packed >> (8 * k)) & 0xffu, pix0 + k);
         }
     }
 }
@@ -930,7 +961,7 @@ __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ 
                                                     uint2 *__restrict__ units, uint32_t *__restrict__ nunits,
                                                     uint32_t *__restrict__ hist, uint8_t *__restrict__ diff,
                                                     const int32_t *__restrict__ cthr, uint32_t *pairs, uint32_t pcap,
-                                                    uint32_t *pcount, uint32_t slot_base)
+                                                    uint32_t *pcount, uint32_t slot_base, SusList gl)
 {
     constexpr int NP = 2 * NDW;
     __shared__ uint32_t pend[K2B_PEND];
@@ -982,7 +1013,7 @@ __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ 
 #pragma unroll
                 for (int g = 0; g < NDW; g++)
                     m[g] = (Xp[2 * g] + Xn[2 * g]) + (Xp[2 * g + 1] + Xn[2 * g + 1]);
-                k2b_row<NDW, false>(J, u, m, tt >= 4 && tt < T, y0 + tt - 4, map, lane, ngroups, budget, pend);
+                k2b_row<NDW, false>(J, u, m, tt >= 4 && tt < T, y0 + tt - 4, map, lane, ngroups, budget, pend, gl);
                 if (STORE && tt >= 4 && tt < T && J.handover < 0 && active)
                     k2b_store_zero_row<NDW>(dbase + (ptrdiff_t)(y0 + tt - 4) * W);
             }
@@ -990,6 +1021,14 @@ __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ 
     }
     if (J.handover >= 0)
         k2b_hand_over(units, nunits, (uint32_t)unit, J.handover, y1, lane);
+    if (J.npend) { // the suspects go to the launch's global list; if that is full the wave evaluates them itself
+        wave_lds_fence();
+        uint32_t gb = 0;
+        if (sus_reserve(J.npend, gl.list, gl.count, gl.cap, gb, lane)) {
+            sus_copy_out(pend, J.npend, J.jidx, gl.list, gb, lane);
+            return;
+        }
+    }
     Compact cp;
     cp.pairs = COMPACT ? pairs : nullptr;
     cp.count = pcount;
@@ -1013,7 +1052,7 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
                                                      const abub_job *__restrict__ jobs, int L, int S, int nslot, int W,
                                                      int H, int rows_per_chunk, int nchunks, uint32_t budget,
                                                      uint2 *__restrict__ units, uint32_t *__restrict__ nunits,
-                                                     uint32_t *__restrict__ hist, uint8_t *__restrict__ diff)
+                                                     uint32_t *__restrict__ hist, uint8_t *__restrict__ diff, SusList gl)
 {
     __shared__ uint32_t pend[K][K2B_PEND];
     const int lane = threadIdx.x;
@@ -1138,7 +1177,7 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
                     for (int g = 0; g < NDW; g++) // sat(c - (r + s)) + sat(r - (c + s)), both pairs of the group
                         m[g] = (pk_subsat(cw[2 * g], ps[2 * g]) + pk_subsat(pw[2 * g], cs[2 * g])) +
                                (pk_subsat(cw[2 * g + 1], ps[2 * g + 1]) + pk_subsat(pw[2 * g + 1], cs[2 * g + 1]));
-                    k2b_row<NDW, SPLIT>(J[t], u, m, tt >= 4 && tt < T, y0 + tt - 4, map, lane, ngroups, budget, pend[t]);
+                    k2b_row<NDW, SPLIT>(J[t], u, m, tt >= 4 && tt < T, y0 + tt - 4, map, lane, ngroups, budget, pend[t], gl);
                     if (STORE && tt >= 4 && tt < T && J[t].handover < 0)
                         map.store_zero(dbase[t] + (ptrdiff_t)(y0 + tt - 4) * W, lane);
                 }
@@ -1151,20 +1190,38 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
         }
     }
 #undef K2C_LOAD
-    Compact cp;
+    uint32_t tot = 0;
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+        if (t < k) {
+            if (J[t].handover >= 0)
+                k2b_hand_over(units, nunits, J[t].jidx * (uint32_t)nchunks + (uint32_t)chunk, J[t].handover, y1, lane);
+            tot += J[t].npend;
+        }
+    }
+    if (tot == 0)
+        return;
+    wave_lds_fence();
+    uint32_t gb = 0;
+    if (sus_reserve(tot, gl.list, gl.count, gl.cap, gb, lane)) { // the whole wave's suspects in one reservation
+#pragma unroll
+        for (int t = 0; t < K; t++)
+            if (t < k) {
+                sus_copy_out(pend[t], J[t].npend, J[t].jidx, gl.list, gb, lane);
+                gb += J[t].npend;
+            }
+        return;
+    }
+    Compact cp; // no room in the global list: the wave evaluates its suspects itself
     cp.pairs = nullptr;
     cp.count = nullptr;
     cp.cap = 0;
     cp.slot = 0;
     cp.thr = 255;
 #pragma unroll
-    for (int t = 0; t < K; t++) {
-        if (t < k) {
-            if (J[t].handover >= 0)
-                k2b_hand_over(units, nunits, J[t].jidx * (uint32_t)nchunks + (uint32_t)chunk, J[t].handover, y1, lane);
+    for (int t = 0; t < K; t++)
+        if (t < k)
             k2b_tail<false, STORE>(pend[t], J[t].npend, jb[t], frames, sigma6, W, H, hist, diff, cp, lane);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1341,6 +1398,10 @@ struct K2Options {
     int budget = 512;  // suspects a chunk may remember (LDS) before it hands its rows over (<= K2B_PEND)
     int pf = 1;        // software-prefetch depth of the row machine in rows (1 or 2)
     int split = 1;     // chained scan: "split" lane mapping where the row width allows it (0: always blocked)
+    int list = 0;      // 1: suspects go to a global list that a second kernel evaluates (sus_tail_list), 0: the scanning
+                       // waves evaluate their own.  K2's exact groups are expensive (45 window loads, two 5x5 sums) and few
+                       // per wave: measured on the bench's trigger pass, in-wave 2.36 ms vs 2.47 ms through the list (K3,
+                       // where every frame has its bubble and a group costs a 3x3 box, is the other way round: list always)
     bool loaded = false;
 };
 static K2Options g_k2opt;
@@ -1360,6 +1421,8 @@ static K2Options k2_options()
             g_k2opt.pf = atoi(e);
         if (const char *e = getenv("ABUB_K2_SPLIT"))
             g_k2opt.split = atoi(e);
+        if (const char *e = getenv("ABUB_K2_LIST"))
+            g_k2opt.list = atoi(e);
         g_k2opt.loaded = true;
     }
     return g_k2opt;
@@ -1381,6 +1444,8 @@ extern "C" int abub_k2_set_option(const char *name, int value)
         g_k2opt.pf = value;
     else if (!strcmp(name, "split"))
         g_k2opt.split = value;
+    else if (!strcmp(name, "list"))
+        g_k2opt.list = value;
     else
         return set_err(ABUB_E_INVALID, "abub_k2_set_option: unknown option or bad value");
     return ABUB_OK;
@@ -1398,14 +1463,25 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
         // a chunk remembers up to `budget` suspicious groups in LDS, then it hands its remaining rows to the row machine
         const uint32_t budget = (uint32_t)(opt.budget < K2B_PEND ? opt.budget : K2B_PEND);
         const size_t unitCap = nunits * (size_t)((R + K2B_SUB - 1) / K2B_SUB); // handed-over pieces, worst case
-        const size_t bytes = 256 + unitCap * sizeof(uint2) + 256;
+        const size_t unitBytes = (unitCap * sizeof(uint2) + 255) & ~(size_t)255;
+        // the global suspect list (see sus_tail_list): room for 1024 groups per job on average within 64 K .. 16 M entries
+        size_t gcap = (size_t)njobs * 1024;
+        gcap = gcap < ((size_t)1 << 16) ? ((size_t)1 << 16) : (gcap > ((size_t)1 << 24) ? ((size_t)1 << 24) : gcap);
+        if (!opt.list)
+            gcap = 0;
+        const size_t bytes = 256 + unitBytes + gcap * sizeof(uint2) + 256;
         std::unique_lock<std::mutex> hold;
         uint8_t *scr = (uint8_t *)k2_scratch(st, bytes, hold);
         if (!scr)
             return set_err(ABUB_E_HIP, "abub_diff_hist_dev: scratch allocation failed");
-        uint32_t *counters = (uint32_t *)scr; // [0] = handed-over pieces
+        uint32_t *counters = (uint32_t *)scr; // [0] = handed-over pieces, [32] = entries of the global suspect list
         uint2 *units = (uint2 *)(scr + 256);
-        HIPCHK(hipMemsetAsync(counters, 0, sizeof(uint32_t), st));
+        SusList gl;
+        gl.list = gcap ? (uint2 *)(scr + 256 + unitBytes) : nullptr;
+        gl.count = counters + 32;
+        gl.cap = (uint32_t)gcap;
+        const unsigned tgrid = (unsigned)((gcap + 256 * SUSL_UB - 1) / (256 * SUSL_UB) < 2048 ? (gcap + 256 * SUSL_UB - 1) / (256 * SUSL_UB) : 2048);
+        HIPCHK(hipMemsetAsync(counters, 0, 256, st));
         const int L = ca.chain_len, S = ca.chain_stride;
         const int chainK = opt.chain < 0 ? (NDW <= 5 ? 3 : 2) : opt.chain;
         if (chainK >= 2 && L > 0 && S > 0 && S <= 8 && njobs % L == 0 && !ca.cthr) {
@@ -1422,14 +1498,15 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
             // lines --; trigger-only equal at 1280 and 2-7 % slower at 1680, where the three segments cost more
             // neighbour-exchange instructions than the loads gain: split there only when D is stored)
             constexpr bool CAN_SPLIT = NDW >= 5 && NDW <= 7;
-            const bool split = CAN_SPLIT && opt.split && split_ndw(W) == NDW && (diff != nullptr || NDW == 5 || opt.split > 1);
+            const bool split = CAN_SPLIT && opt.split && (diff != nullptr || NDW == 5 || opt.split > 1);
+#define K2C_ARGS frames, sigma6, jobs, L, S, nslot, W, H, R, nchunks, budget, units, counters, hist, diff, gl
+#define K2C_LAUNCH_SP(KK, ST, SP) hipLaunchKernelGGL((k2_bound_chain<NDW, KK, ST, SP>), grid, dim3(64), 0, st, K2C_ARGS)
 #define K2C_LAUNCH(KK, ST)                                                                                          \
-    if (split)                                                                                                      \
-        hipLaunchKernelGGL((k2_bound_chain<NDW, KK, ST, CAN_SPLIT>), grid, dim3(64), 0, st, frames, sigma6, jobs, L, \
-                           S, nslot, W, H, R, nchunks, budget, units, counters, hist, diff);                        \
-    else                                                                                                            \
-        hipLaunchKernelGGL((k2_bound_chain<NDW, KK, ST, false>), grid, dim3(64), 0, st, frames, sigma6, jobs, L, S, \
-                           nslot, W, H, R, nchunks, budget, units, counters, hist, diff)
+    if (split) {                                                                                                    \
+        K2C_LAUNCH_SP(KK, ST, CAN_SPLIT);                                                                           \
+    } else {                                                                                                        \
+        K2C_LAUNCH_SP(KK, ST, false);                                                                               \
+    }
             if (Kc == 3) {
                 if (diff) {
                     K2C_LAUNCH(3, true);
@@ -1443,12 +1520,14 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
                     K2C_LAUNCH(2, false);
                 }
             }
+#undef K2C_LAUNCH_SP
+#undef K2C_ARGS
 #undef K2C_LAUNCH
         } else {
 #define K2S_LAUNCH(ST, CO)                                                                                          \
     hipLaunchKernelGGL((k2_bound_scan<NDW, ST, CO>), dim3((unsigned)nunits), dim3(64), 0, st, frames, sigma6, jobs, \
                        W, H, R, nchunks, budget, units, counters, hist, diff, ca.cthr, ca.pairs, ca.cap, ca.count,  \
-                       ca.slot_base)
+                       ca.slot_base, gl)
             if (ca.cthr) {
                 if (diff)
                     K2S_LAUNCH(true, true);
@@ -1461,6 +1540,27 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
                     K2S_LAUNCH(false, false);
             }
 #undef K2S_LAUNCH
+        }
+        // the suspects of all scanning waves, evaluated exactly (after the scan: in store mode it overwrites zero rows)
+        if (gl.list) {
+#define K2T_LAUNCH(CO, ST)                                                                                          \
+    hipLaunchKernelGGL((sus_tail_list<2, CO, ST>), dim3(tgrid), dim3(256), 0, st, frames, (const uint8_t *)nullptr,  \
+                       sigma6, jobs, W, H, hist, diff, gl.list, gl.count, gl.cap, ca.cthr, ca.pairs, ca.cap, ca.count, \
+                       ca.slot_base)
+            if (ca.cthr) {
+                if (diff) {
+                    K2T_LAUNCH(true, true);
+                } else {
+                    K2T_LAUNCH(true, false);
+                }
+            } else {
+                if (diff) {
+                    K2T_LAUNCH(false, true);
+                } else {
+                    K2T_LAUNCH(false, false);
+                }
+            }
+#undef K2T_LAUNCH
         }
         // the handed-over row ranges through the row machine's list mode (grid-stride over the pieces); with the fused
         // candidate list (cthr) it emits the candidates, with `diff` it writes its rows
@@ -2052,7 +2152,53 @@ struct K3ScanJob {
     int skipTo; // output rows below this one belong to the row machine (a piece was handed over) or are not this job's
 };
 
-// exact O for the four pixels of every remembered group (L3Localizer.cpp:779-785): one lane per group
+// exact O for the four pixels of 4-pixel group (y, x0) (L3Localizer.cpp:779-785), packed one value per byte.
+// Interior groups read their 6-pixel window as three aligned dwords per array and row (the pixels x0-1 .. x0+4 are
+// bytes 3 .. 8 of the 12 bytes from x0-4); the two edge groups (reflected columns) go byte by byte.
+__device__ __forceinline__ uint32_t k3_exact_group(const uint8_t *__restrict__ f, const uint8_t *__restrict__ m,
+                                                   const uint8_t *__restrict__ sg, int y, int x0, int W, int H)
+{
+    const bool interior = x0 >= 4 && x0 + 8 <= W;
+    int S[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const size_t ro = (size_t)reflect101(y - 1 + i, H) * W;
+        int o[6];
+        if (interior) {
+            const uint32_t *pf = reinterpret_cast<const uint32_t *>(f + ro + x0 - 4);
+            const uint32_t *pm = reinterpret_cast<const uint32_t *>(m + ro + x0 - 4);
+            const uint32_t *ps = reinterpret_cast<const uint32_t *>(sg + ro + x0 - 4);
+            const uint32_t fw[3] = {pf[0], pf[1], pf[2]}, mw[3] = {pm[0], pm[1], pm[2]}, sw[3] = {ps[0], ps[1], ps[2]};
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const int q = (3 + j) >> 2, sh = 8 * ((3 + j) & 3);
+                int a = (int)((fw[q] >> sh) & 0xff) - (int)((mw[q] >> sh) & 0xff);
+                a = a < 0 ? -a : a;
+                a -= (int)((sw[q] >> sh) & 0xff);
+                o[j] = a < 0 ? 0 : a;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const int x = reflect101(x0 - 1 + j, W);
+                int a = (int)f[ro + x] - (int)m[ro + x];
+                a = a < 0 ? -a : a;
+                a -= (int)sg[ro + x];
+                o[j] = a < 0 ? 0 : a;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            S[q] += o[q] + o[q + 1] + o[q + 2];
+    }
+    uint32_t packed = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        packed |= ((uint32_t)(S[q] + 4) / 9u) << (8 * q);
+    return packed;
+}
+
+// the wave's own tail (no global list, or it is full): one lane per remembered group
 template <bool COMPACT, bool STORE>
 __device__ __forceinline__ void k3s_tail(const uint32_t *pend, uint32_t npend, const abub_job jb, const uint8_t *__restrict__ frames,
                                          const uint8_t *__restrict__ mu, const uint8_t *__restrict__ sigma6, int W, int H,
@@ -2060,7 +2206,7 @@ __device__ __forceinline__ void k3s_tail(const uint32_t *pend, uint32_t npend, c
 {
     if (npend == 0)
         return;
-    __syncthreads(); // (one wave: orders the LDS writes of the scan before the reads below)
+    wave_lds_fence(); // orders the scan's LDS writes before the reads below
     const size_t P = (size_t)W * H;
     const uint32_t ngroups = (uint32_t)W / 4;
     const uint8_t *f = frames + (size_t)jb.cur * P;
@@ -2069,70 +2215,179 @@ __device__ __forceinline__ void k3s_tail(const uint32_t *pend, uint32_t npend, c
     const uint32_t nloop = COMPACT ? (npend + 63u) & ~63u : npend;
 #pragma unroll 1
     for (uint32_t e = lane; e < nloop; e += 64) {
-        uint32_t Ov[4] = {0, 0, 0, 0};
-        uint32_t pix0 = 0;
+        uint32_t packed = 0, pix0 = 0;
         if (e < npend) {
             const uint32_t code = pend[e];
             const int y = (int)(code / ngroups), x0 = (int)(code % ngroups) * 4;
-            // interior groups read their 6-pixel window as three aligned dwords per array and row (the pixels x0-1 ..
-            // x0+4 are bytes 3 .. 8 of the 12 bytes from x0-4); the two edge groups (reflected columns) go byte by byte
-            const bool interior = x0 >= 4 && x0 + 8 <= W;
-            int xs[6];
-#pragma unroll
-            for (int j = 0; j < 6; j++)
-                xs[j] = reflect101(x0 - 1 + j, W);
-            int S[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const size_t ro = (size_t)reflect101(y - 1 + i, H) * W;
-                int o[6];
-                if (interior) {
-                    const uint32_t *pf = reinterpret_cast<const uint32_t *>(f + ro + x0 - 4);
-                    const uint32_t *pm = reinterpret_cast<const uint32_t *>(m + ro + x0 - 4);
-                    const uint32_t *ps = reinterpret_cast<const uint32_t *>(sg + ro + x0 - 4);
-                    const uint32_t fw[3] = {pf[0], pf[1], pf[2]}, mw[3] = {pm[0], pm[1], pm[2]}, sw[3] = {ps[0], ps[1], ps[2]};
-#pragma unroll
-                    for (int j = 0; j < 6; j++) {
-                        const int q = (3 + j) >> 2, sh = 8 * ((3 + j) & 3);
-                        int a = (int)((fw[q] >> sh) & 0xff) - (int)((mw[q] >> sh) & 0xff);
-                        a = a < 0 ? -a : a;
-                        a -= (int)((sw[q] >> sh) & 0xff);
-                        o[j] = a < 0 ? 0 : a;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 6; j++) {
-                        int a = (int)f[ro + xs[j]] - (int)m[ro + xs[j]];
-                        a = a < 0 ? -a : a;
-                        a -= (int)sg[ro + xs[j]];
-                        o[j] = a < 0 ? 0 : a;
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    S[q] += o[q] + o[q + 1] + o[q + 2];
-            }
+            packed = k3_exact_group(f, m, sg, y, x0, W, H);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const uint32_t v = (uint32_t)(S[q] + 4) / 9u;
-                Ov[q] = v;
+                const uint32_t v = (packed >> (8 * q)) & 0xffu;
                 if (v)
                     atomicAdd(&hist[(size_t)jb.out * 256 + v], 1u);
             }
             if (STORE)
-                *reinterpret_cast<uint32_t *>(img + (size_t)jb.out * P + (size_t)y * W + x0) =
-                    Ov[0] | (Ov[1] << 8) | (Ov[2] << 16) | (Ov[3] << 24);
+                *reinterpret_cast<uint32_t *>(img + (size_t)jb.out * P + (size_t)y * W + x0) = packed;
             pix0 = (uint32_t)(y * W + x0);
         }
         if (COMPACT) {
             uint32_t c = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                c += (int)Ov[q] > cp.thr;
+                c += (int)((packed >> (8 * q)) & 0xffu) > cp.thr;
             uint32_t pos = compact_reserve(cp, c);
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                compact_put(cp, pos, Ov[q], pix0 + q);
+                compact_put(cp, pos, (packed >> (8 * q)) & 0xffu, pix0 + q);
+        }
+    }
+}
+
+// ---- sus_tail_list: the second kernel of a bound-and-verify launch ------------------------------------------------
+// The exact evaluation of a suspect group is a chain of dependent latencies (LDS code -> window loads -> values ->
+// candidate-list reservation -> stores): done by the scanning wave itself it holds a wave slot for about as long as
+// the scan did -- every tracking frame has its bubble -- and with the fused candidate list it costs one reservation
+// on the shared counter per 64 groups (that counter serialises at ~90 atomics / us).  So the scanning waves only MOVE
+// their LDS lists to the global list (one reservation per wave, or per overflowing LDS list), and this kernel
+// evaluates all of it with the whole chip: one lane per group, up to four consecutive groups per lane, one
+// candidate-list reservation per block iteration.  KIND 2: D of ProcessFrame (mu unused), KIND 3: O of the tracking
+// frames.  When the global list is full the scanning wave evaluates its groups itself (k2b_tail / k3s_tail).
+template <int KIND, bool COMPACT, bool STORE>
+__global__ __launch_bounds__(256) void sus_tail_list(const uint8_t *__restrict__ frames, const uint8_t *__restrict__ mu,
+                                                     const uint8_t *__restrict__ sigma6, const abub_job *__restrict__ jobs,
+                                                     int W, int H, uint32_t *__restrict__ hist, uint8_t *__restrict__ img,
+                                                     const uint2 *__restrict__ glist, const uint32_t *__restrict__ gcount,
+                                                     uint32_t gcap, const int32_t *__restrict__ cthr, uint32_t *pairs,
+                                                     uint32_t pcap, uint32_t *pcount, uint32_t slot_base)
+{
+    __shared__ uint32_t wtot[4], bbase;
+    // histogram counts of the wave's leading job are gathered in LDS and added to memory once per bin: a bubble's
+    // pixels share a few values, and thousands of same-address atomics per frame serialise in the L2
+    __shared__ uint32_t lh[4][256];
+    uint32_t n = *gcount;
+    if (n > gcap)
+        n = gcap;
+    const size_t P = (size_t)W * H;
+    const uint32_t ngroups = (uint32_t)W / 4;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // entries per lane and block iteration: as few as keeps every block busy (short lists: more blocks in flight, shorter
+    // latency chains), at most SUSL_UB (long lists: few reservations on the shared candidate list)
+    uint32_t KE = (n + gridDim.x * 256u - 1u) / (gridDim.x * 256u);
+    KE = KE < 1u ? 1u : (KE > SUSL_UB ? (uint32_t)SUSL_UB : KE);
+    const uint32_t PER = 256u * KE;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        lh[wv][4 * lane + q] = 0;
+    for (uint32_t e0 = blockIdx.x * PER; e0 < n; e0 += gridDim.x * PER) {
+        uint32_t Ov[SUSL_UB], pix0[SUSL_UB], slot[SUSL_UB];
+        int thr[SUSL_UB];
+        uint32_t c = 0;
+        // the wave's leading job = the job of its first entry (most of the wave's consecutive entries belong to it)
+        uint32_t job0 = 0xffffffffu;
+        {
+            const uint32_t ef = e0 + (uint32_t)(wv * 64) * KE;
+            if (ef < n)
+                job0 = glist[ef].x;
+            job0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)job0);
+        }
+        // entries and their job records first (independent loads), then the windows
+        uint2 ens[SUSL_UB];
+        abub_job jbs[SUSL_UB];
+#pragma unroll
+        for (int u = 0; u < SUSL_UB; u++) {
+            // consecutive entries per lane: the candidate list keeps the producers' runs of equal slots (k_pairs_scatter
+            // reserves once per run)
+            const uint32_t e = e0 + (uint32_t)tid * KE + (uint32_t)u;
+            ens[u] = make_uint2(0xffffffffu, 0u);
+            if ((uint32_t)u < KE && e < n)
+                ens[u] = glist[e];
+        }
+#pragma unroll
+        for (int u = 0; u < SUSL_UB; u++)
+            jbs[u] = jobs[ens[u].x != 0xffffffffu ? ens[u].x : 0u];
+#pragma unroll
+        for (int u = 0; u < SUSL_UB; u++) {
+            Ov[u] = 0;
+            pix0[u] = 0;
+            slot[u] = 0;
+            thr[u] = 255;
+            const uint2 en = ens[u];
+            if (en.x != 0xffffffffu) {
+                const abub_job jb = jbs[u];
+                const int y = (int)(en.y / ngroups), x0 = (int)(en.y % ngroups) * 4;
+                uint32_t packed;
+                if (KIND == 2)
+                    packed = k2_exact_group(frames + (size_t)jb.cur * P, frames + (size_t)jb.ref * P,
+                                            sigma6 + (size_t)jb.model * P, y, x0, W, H);
+                else
+                    packed = k3_exact_group(frames + (size_t)jb.cur * P, mu + (size_t)jb.model * P,
+                                            sigma6 + (size_t)jb.model * P, y, x0, W, H);
+                if (COMPACT)
+                    thr[u] = cthr[jb.out];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t v = (packed >> (8 * q)) & 0xffu;
+                    if (v) {
+                        if (en.x == job0)
+                            atomicAdd(&lh[wv][v], 1u);
+                        else
+                            atomicAdd(&hist[(size_t)jb.out * 256 + v], 1u);
+                    }
+                    c += COMPACT && (int)v > thr[u];
+                }
+                if (STORE) // (the scan wrote this row as zeros; an aligned dword)
+                    *reinterpret_cast<uint32_t *>(img + (size_t)jb.out * P + (size_t)y * W + x0) = packed;
+                Ov[u] = packed;
+                pix0[u] = (uint32_t)(y * W + x0);
+                slot[u] = jb.out + slot_base;
+            }
+        }
+        if (job0 != 0xffffffffu) { // the gathered counts: four bins per lane
+            wave_lds_fence();
+            const size_t hb = (size_t)jobs[job0].out * 256;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t cnt = lh[wv][4 * lane + q];
+                if (cnt) {
+                    atomicAdd(&hist[hb + 4 * lane + q], cnt);
+                    lh[wv][4 * lane + q] = 0;
+                }
+            }
+            wave_lds_fence();
+        }
+        if (COMPACT) { // one reservation on the shared candidate list per block iteration
+            uint32_t inc = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(inc, o);
+                if (lane >= o)
+                    inc += t;
+            }
+            if (lane == 63)
+                wtot[wv] = inc;
+            __syncthreads();
+            if (tid == 0) {
+                const uint32_t tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+                bbase = tot ? atomicAdd(pcount, tot) : 0u;
+            }
+            __syncthreads();
+            uint32_t pos = bbase + inc - c;
+            for (int w = 0; w < wv; w++)
+                pos += wtot[w];
+#pragma unroll
+            for (int u = 0; u < SUSL_UB; u++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t v = (Ov[u] >> (8 * q)) & 0xffu;
+                    if ((int)v > thr[u]) {
+                        if (pos < pcap) {
+                            pairs[2 * (size_t)pos] = slot[u] | (v << 24);
+                            pairs[2 * (size_t)pos + 1] = pix0[u] + q;
+                        }
+                        ++pos;
+                    }
+                }
+            __syncthreads(); // wtot / bbase are rewritten by the next iteration
         }
     }
 }
@@ -2145,7 +2400,8 @@ __global__ __launch_bounds__(64) void k3_bound_scan(const uint8_t *__restrict__ 
                                                     uint8_t *__restrict__ img, uint2 *__restrict__ pieces,
                                                     uint32_t *__restrict__ npieces, const int32_t *__restrict__ cthr,
                                                     uint32_t *pairs, uint32_t pcap, uint32_t *pcount, uint32_t slot_base,
-                                                    uint32_t budget)
+                                                    uint32_t budget, uint2 *__restrict__ glist,
+                                                    uint32_t *__restrict__ gcount, uint32_t gcap)
 {
     constexpr int NP = 2 * NDW;
     constexpr int NG = K3ScanJob<NDW>::NG, GS = K3ScanJob<NDW>::GS;
@@ -2272,8 +2528,20 @@ __global__ __launch_bounds__(64) void k3_bound_scan(const uint8_t *__restrict__ 
                         total += (uint32_t)nq * (uint32_t)__builtin_popcountll(bm[g]);
                     }
                     J[t].hot += total > 32u;
+                    if (J[t].hot < 4u && J[t].npend + total > budget && total <= budget) {
+                        // the LDS list is full: move it to the launch's global list and go on with an empty one
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        uint32_t gb = 0;
+                        if (sus_reserve(J[t].npend, glist, gcount, gcap, gb, lane)) {
+                            sus_copy_out(pend[t], J[t].npend, (uint32_t)(j0 + t), glist, gb, lane);
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            J[t].npend = 0;
+                        }
+                    }
                     if (J[t].hot >= 4u || J[t].npend + total > budget) {
-                        // dense rows (or the LDS list is full): the next K2B_SUB rows go to the row machine as one
+                        // dense rows (or no room anywhere): the next K2B_SUB rows go to the row machine as one
                         // piece; the scan goes on underneath and takes over again after them
                         const int ye = y + K2B_SUB < y1 ? y + K2B_SUB : y1;
                         k2b_hand_over(pieces, npieces, (uint32_t)(j0 + t), y, ye, lane);
@@ -2311,6 +2579,26 @@ __global__ __launch_bounds__(64) void k3_bound_scan(const uint8_t *__restrict__ 
         }
     }
 #undef K3S_LOAD
+    {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int t = 0; t < KF; t++)
+            tot += t < k ? J[t].npend : 0u;
+        if (tot == 0)
+            return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t gb = 0;
+        if (sus_reserve(tot, glist, gcount, gcap, gb, lane)) { // the whole wave's suspects in one reservation
+#pragma unroll
+            for (int t = 0; t < KF; t++)
+                if (t < k) {
+                    sus_copy_out(pend[t], J[t].npend, (uint32_t)(j0 + t), glist, gb, lane);
+                    gb += J[t].npend;
+                }
+            return;
+        }
+    }
 #pragma unroll
     for (int t = 0; t < KF; t++) {
         if (t < k) {
@@ -2347,13 +2635,27 @@ static int launch_k3_rows(const uint8_t *frames, const uint8_t *mu, const uint8_
         constexpr int KF = NDW <= 5 ? 5 : (NDW <= 7 ? 4 : 3); // jobs per scanning wave (register budget)
         const size_t nunits = (size_t)njobs * nchunks;
         const size_t cap = nunits * (size_t)((R + K2B_SUB - 1) / K2B_SUB); // handed-over pieces, worst case
+        // the global suspect list (see sus_tail_list): room for 2048 groups per frame on average -- the footprint of a
+        // tracked bubble is a few hundred to a thousand groups -- within 64 K .. 16 M entries
+        static int k3list = -1;
+        if (k3list < 0) {
+            const char *e = getenv("ABUB_K3_LIST"); // 0: suspects are evaluated by the scanning waves themselves
+            k3list = e ? atoi(e) : 1;
+        }
+        size_t gcap = (size_t)njobs * 2048;
+        gcap = gcap < ((size_t)1 << 16) ? ((size_t)1 << 16) : (gcap > ((size_t)1 << 24) ? ((size_t)1 << 24) : gcap);
+        if (!k3list)
+            gcap = 0;
+        const size_t piecesBytes = (cap * sizeof(uint2) + 255) & ~(size_t)255;
         std::unique_lock<std::mutex> hold;
-        uint8_t *scr = (uint8_t *)k2_scratch(st, 256 + cap * sizeof(uint2) + 256, hold);
+        uint8_t *scr = (uint8_t *)k2_scratch(st, 256 + piecesBytes + gcap * sizeof(uint2) + 256, hold);
         if (!scr)
             return set_err(ABUB_E_HIP, "abub_posttrig_dev: scratch allocation failed");
-        uint32_t *counter = (uint32_t *)scr;
+        uint32_t *counter = (uint32_t *)scr;   // [0] = handed-over pieces, [32] = entries of the global suspect list
+        uint32_t *gcount = counter + 32;
         uint2 *pieces = (uint2 *)(scr + 256);
-        HIPCHK(hipMemsetAsync(counter, 0, sizeof(uint32_t), st));
+        uint2 *glist = gcap ? (uint2 *)(scr + 256 + piecesBytes) : nullptr;
+        HIPCHK(hipMemsetAsync(counter, 0, 256, st));
         const dim3 sgrid((unsigned)((size_t)((njobs + KF - 1) / KF) * nchunks));
         static int k3b = -1;
         if (k3b < 0) {
@@ -2365,17 +2667,24 @@ static int launch_k3_rows(const uint8_t *frames, const uint8_t *mu, const uint8_
         const uint32_t k3budget = (uint32_t)k3b;
 #define K3S_LAUNCH(ST, CO)                                                                                          \
     hipLaunchKernelGGL((k3_bound_scan<NDW, KF, ST, CO>), sgrid, dim3(64), 0, st, frames, mu, sigma6, jobs, njobs, W, \
-                       H, R, nchunks, hist, img, pieces, counter, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base, k3budget)
+                       H, R, nchunks, hist, img, pieces, counter, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base, \
+                       k3budget, glist, gcount, (uint32_t)gcap);                                                    \
+    if (glist)                                                                                                      \
+    hipLaunchKernelGGL((sus_tail_list<3, CO, ST>), dim3(tgrid), dim3(256), 0, st, frames, mu, sigma6, jobs, W, H, hist, \
+                       img, glist, gcount, (uint32_t)gcap, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base)
+        const unsigned tgrid = (unsigned)((gcap + 256 * SUSL_UB - 1) / (256 * SUSL_UB) < 2048 ? (gcap + 256 * SUSL_UB - 1) / (256 * SUSL_UB) : 2048);
         if (ca.cthr) {
-            if (img)
+            if (img) {
                 K3S_LAUNCH(true, true);
-            else
+            } else {
                 K3S_LAUNCH(false, true);
+            }
         } else {
-            if (img)
+            if (img) {
                 K3S_LAUNCH(true, false);
-            else
+            } else {
                 K3S_LAUNCH(false, false);
+            }
         }
 #undef K3S_LAUNCH
         const unsigned g = (unsigned)(cap < 8192 ? cap : 8192);

@@ -129,7 +129,9 @@ int abub_diff_hist_chained_store_dev(const uint8_t *frames, const uint8_t *sigma
  *   "bound"  1 = bound-and-verify pass (default), 0 = the plain row machine for every row (the dense-regime worst case)
  *   "chain"  jobs per wave of the chained scan: 2 or 3; 0 = never chain; -1 (default) = 3 for W <= 1280, else 2
  *   "split"  1 (default) = the chained scan's whole-piece lane mapping where it pays, 0 = never, 2 = wherever possible
- *   "budget" suspects a chunk may list before it hands its remaining rows to the row machine
+ *   "budget" suspect groups a (job, chunk) may list in LDS before it hands its remaining rows to the row machine
+ *   "list"   1 = suspect groups go to a global list that a second kernel evaluates exactly with the whole chip;
+ *            0 (default) = every scanning wave evaluates its own suspects at its end
  *   "pf"     software-prefetch depth of the row machine (1 or 2)
  * Results never depend on them. */
 int abub_k2_set_option(const char *name, int value);

@@ -19,6 +19,7 @@ def _k2_defaults():
     hip.k2_set_option("chain", -1)
     hip.k2_set_option("budget", 1024)
     hip.k2_set_option("split", 1)
+    hip.k2_set_option("list", 0)
 
 
 def rnd_frames(rs, n, H, W, base=None, amp=12):
@@ -57,16 +58,19 @@ def test_k2_diff_hist_parity(oracle, H, W, R):
     assert np.array_equal(s6.cpu().numpy(), np.minimum(6 * sigma.astype(int), 255).astype(np.uint8))
     j_d = hip.make_jobs(jobs, DEV)
     # bound = 1: bound-and-verify pass (scan + exact groups + handed-over rows), bound = 0: the row machine alone;
-    # budget 8 forces hand-overs in the middle of chunks
-    for bound, budget in ((1, 1024), (0, 1024), (1, 8)):
+    # budget 8 fills the per-chunk LDS lists in the middle of chunks (the rest of the chunk is handed to the row
+    # machine); list = 1: the listed suspects go to the launch's global list and sus_tail_list evaluates them,
+    # list = 0: the scanning waves evaluate their suspects themselves
+    for bound, budget, lst in ((1, 1024, 1), (0, 1024, 1), (1, 8, 1), (1, 1024, 0), (1, 8, 0)):
         hip.k2_set_option("bound", bound)
         hip.k2_set_option("budget", budget)
+        hip.k2_set_option("list", lst)
         for store in (True, False):
             hist, diff = hip.diff_hist(f_d, s6, j_d, W, H, store=store, rows_per_chunk=R)
             torch.cuda.synchronize()
-            assert np.array_equal(hist.cpu().numpy().astype(np.uint32), href), (H, W, store, bound, budget)
+            assert np.array_equal(hist.cpu().numpy().astype(np.uint32), href), (H, W, store, bound, budget, lst)
             if store:
-                assert np.array_equal(diff.cpu().numpy(), Dref), (H, W, bound, budget)
+                assert np.array_equal(diff.cpu().numpy(), Dref), (H, W, bound, budget, lst)
 
 
 def test_k2_extreme_values(oracle):
@@ -122,11 +126,14 @@ def test_k2_trigger_only_bound_and_verify(oracle, H, W, R):
     assert np.array_equal(hist.cpu().numpy().astype(np.uint32), href)
     # store mode of the same pass: the scan writes the zero rows, the exact groups their pixels
     Dref, _ = oracle_hists(oracle, frames, sigma, jobs)
-    for budget in (1024, 16):
+    for budget, lst in ((1024, 1), (16, 1), (1024, 0), (16, 0)):
         hip.k2_set_option("budget", budget)
+        hip.k2_set_option("list", lst)
         hist, D = hip.diff_hist(f_d, s6, hip.make_jobs(jobs, DEV), W, H, store=True, rows_per_chunk=R)
         assert np.array_equal(hist.cpu().numpy().astype(np.uint32), href)
-        assert np.array_equal(D.cpu().numpy(), Dref), budget
+        assert np.array_equal(D.cpu().numpy(), Dref), (budget, lst)
+        hist, _ = hip.diff_hist(f_d, s6, hip.make_jobs(jobs, DEV), W, H, store=False, rows_per_chunk=R)
+        assert np.array_equal(hist.cpu().numpy().astype(np.uint32), href), (budget, lst)
 
 
 def test_k2_stack_jobs_and_synthetic_event(oracle):
@@ -203,6 +210,63 @@ def test_k3_posttrig_parity(oracle, H, W):
         O = oracle.posttrig_frame(fr[c], mu[m], sg[m])
         assert np.array_equal(img[o].cpu().numpy(), O)
         assert np.array_equal(hist[o].cpu().numpy().astype(np.uint32), oracle.hist256(O))
+
+
+def test_k3_suspect_list_paths(oracle):
+    """K3's suspect groups travel from the scanning waves to a global list that a second kernel evaluates
+    (k3_tail_list).  Full-height frames with five narrow vertical stripes -- about 30 suspect groups in every row, so rows
+    are never 'hot' -- fill the per-chunk LDS lists (flushes in mid-scan) and, with three jobs, overflow the global
+    list's minimum capacity of 64 K entries (the scanning waves then evaluate the rest themselves); a tracked-bubble
+    frame and a quiet frame go through the ordinary path.  Image, histogram and fused candidate list == oracle."""
+    import ctypes as C
+
+    from autobub3hs_amd import _lib
+
+    W, H = 1280, 1024
+    rs = np.random.RandomState(5)
+    mu = rs.randint(40, 180, (1, H, W)).astype(np.uint8)
+    sg = np.ones((1, H, W), np.uint8)
+    sg[0, ::97, ::89] = 0  # a few hot pixels (sigma 0)
+    fr = np.repeat(mu, 5, axis=0).astype(np.int32) + rs.randint(-1, 2, (5, H, W))
+    for k in range(3):  # stripes, 9 px wide, different phase per frame
+        for x in range(40 + 13 * k, W - 20, 250):
+            fr[k, :, x:x + 9] += 30 + k
+    yy, xx = np.ogrid[:H, :W]
+    fr[3][(yy - 500) ** 2 + (xx - 700) ** 2 <= 45 ** 2] += 50
+    fr = np.clip(fr, 0, 255).astype(np.uint8)
+    jobs = [(k, 0, 0, k) for k in range(5)]
+    f_d, mu_d = torch.from_numpy(fr).to(DEV), torch.from_numpy(mu).to(DEV)
+    s6 = hip.sigma6(torch.from_numpy(sg).to(DEV))
+    j_d = hip.make_jobs(jobs, DEV)
+    hist, img = hip.posttrig(f_d, mu_d, s6, j_d, W, H)
+    O = [oracle.posttrig_frame(fr[k], mu[0], sg[0]) for k in range(5)]
+    for k in range(5):
+        assert np.array_equal(img[k].cpu().numpy(), O[k]), k
+        assert np.array_equal(hist[k].cpu().numpy().astype(np.uint32), oracle.hist256(O[k])), k
+    assert int((O[0] > 0).sum()) > 5 * 7 * H and int((O[4] > 0).sum()) < 100
+    L = _lib.lib()
+    cap = 1 << 21
+    pairs = torch.zeros((cap, 2), dtype=torch.int32, device=DEV)
+    count = torch.zeros((1,), dtype=torch.int32, device=DEV)
+    cthr = torch.tensor([3, 0, 5, 3, 3], dtype=torch.int32, device=DEV)
+    hist3 = torch.empty((5, 256), dtype=torch.int32, device=DEV)
+    _lib.check(L.abub_posttrig_compact_dev(f_d.data_ptr(), mu_d.data_ptr(), s6.data_ptr(), j_d.data_ptr(), 5, W, H,
+                                           hist3.data_ptr(), None, cthr.data_ptr(), pairs.data_ptr(), cap,
+                                           count.data_ptr(), 7, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    n = int(count.item())
+    assert n < cap
+    pr = pairs[:n].cpu().numpy().astype(np.uint32)
+    assert torch.equal(hist3, hist)
+    total = 0
+    for k in range(5):
+        sel = pr[(pr[:, 0] & 0xFFFFFF) == 7 + k]
+        exp = np.flatnonzero(O[k].ravel() > int(cthr[k]))
+        order = np.argsort(sel[:, 1])
+        assert np.array_equal(sel[order, 1], exp), k
+        assert np.array_equal((sel[order, 0] >> 24).astype(np.uint8), O[k].ravel()[exp]), k
+        total += len(exp)
+    assert total == n
 
 
 def test_k4_foreground_compaction(oracle):
@@ -323,6 +387,11 @@ def test_k2_trigger_only_equals_store_mode_full_size(W, H):
     h_cstore, D_c = hip.diff_hist(fr, s6, jobs, W, H, store=True, chain=(F - 1, 2))  # chained scan, store mode
     hip.k2_set_option("chain", 3)
     h_c3, D_c3 = hip.diff_hist(fr, s6, jobs, W, H, store=True, chain=(F - 1, 2))
+    hip.k2_set_option("list", 1)  # suspects through the global list and sus_tail_list instead of the in-wave tails
+    h_l1, D_l1 = hip.diff_hist(fr, s6, jobs, W, H, store=True, chain=(F - 1, 2))
+    h_l1t, _ = hip.diff_hist(fr, s6, jobs, W, H, store=False)
+    assert torch.equal(h_l1, h_c3) and torch.equal(D_l1, D_c3) and torch.equal(h_l1t, h_c3)
+    hip.k2_set_option("list", 0)
     hip.k2_set_option("bound", 0)
     h_store, D = hip.diff_hist(fr, s6, jobs, W, H, store=True)  # the row machine alone
     torch.cuda.synchronize()
@@ -364,17 +433,18 @@ def test_k2_chained_trigger_pass(oracle, W, H, F, off):
     Dref, _ = oracle_hists(oracle, frames, sigma, [tuple(r) for r in jn])
     # chain = jobs per wave; split = the scan's lane mapping (whole 16/8/4-byte pieces per lane where the width allows
     # it -- 1280 {4,1}, 1400 {4,2}, 1540 / 1680 / 1792 {4,2,1}, 1100 {4,1} with a partial last segment -- or blocked)
-    for K, split in ((2, 2), (3, 2), (2, 0), (-1, 1)):
+    for K, split, lst in ((2, 2, 1), (3, 2, 1), (2, 0, 1), (-1, 1, 1), (3, 2, 0), (2, 0, 0)):
         hip.k2_set_option("chain", K)
         hip.k2_set_option("split", split)
+        hip.k2_set_option("list", lst)  # 0: the scanning waves evaluate their suspects themselves
         for L, S in [(F - 1, off), (F - 1, off + 1), (F - 1, 1), ((F - 1) * nst, off), (1, 1)]:
             if ((F - 1) * nst) % L:
                 continue
             got, _ = hip.diff_hist(f_d, s6, jobs, W, H, chain=(L, S))
-            assert torch.equal(got, plain), (K, split, L, S)
+            assert torch.equal(got, plain), (K, split, lst, L, S)
             got, D = hip.diff_hist(f_d, s6, jobs, W, H, chain=(L, S), store=True)
-            assert torch.equal(got, plain), (K, split, L, S)
-            assert np.array_equal(D.cpu().numpy(), Dref), (K, split, L, S)
+            assert torch.equal(got, plain), (K, split, lst, L, S)
+            assert np.array_equal(D.cpu().numpy(), Dref), (K, split, lst, L, S)
 
 
 def test_scratch_release_and_reuse():

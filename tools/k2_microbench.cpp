@@ -47,6 +47,7 @@ int main(int argc, char **argv)
     int R = argc > 6 ? atoi(argv[6]) : 0;
     int chain = argc > 8 ? atoi(argv[8]) : 1; // 1: pass the chain hint (jobs f, f+2 share a frame), 0: plain job list
     int sig = argc > 7 ? atoi(argv[7]) : 1; // model sigma: 1 -> ~3.5 supra-threshold noise pixels per row, 2 -> none
+    int co = argc > 12 ? atoi(argv[12]) : 0; // K3 only: 1 = with the fused candidate list (cut 3 for every frame)
     int k3 = argc > 11 ? atoi(argv[11]) : 0; // 1: time K3 (post-trigger image + histogram, no store) over the same frames
     int discs = argc > 10 ? atoi(argv[10]) : 1; // 0: noise only (no growing discs)
     int cyc = argc > 9 ? atoi(argv[9]) : 0; // > 0: the jobs cycle through the first `cyc` frames only (L2-resident inputs:
@@ -93,13 +94,29 @@ int main(int argc, char **argv)
         uint8_t *mu;
         CK(hipMalloc(&mu, P));
         CK(hipMemcpy(mu, slab, P, hipMemcpyDeviceToDevice));
-        AK(abub_posttrig_dev(slab, mu, sigma6, jobs, njobs, W, H, hist, nullptr, nullptr));
+        int32_t *cthr = nullptr;
+        uint32_t *pairs = nullptr, *pcount = nullptr;
+        const uint32_t pcap = 32u << 20;
+        if (co) {
+            std::vector<int32_t> hc(njobs, 3);
+            CK(hipMalloc(&cthr, njobs * sizeof(int32_t)));
+            CK(hipMemcpy(cthr, hc.data(), njobs * sizeof(int32_t), hipMemcpyHostToDevice));
+            CK(hipMalloc(&pairs, (size_t)pcap * 8));
+            CK(hipMalloc(&pcount, 256));
+        }
+#define K3_CALL()                                                                                                   \
+    if (co) {                                                                                                       \
+        CK(hipMemsetAsync(pcount, 0, 4, 0));                                                                        \
+        AK(abub_posttrig_compact_dev(slab, mu, sigma6, jobs, njobs, W, H, hist, nullptr, cthr, pairs, pcap, pcount, 0, nullptr)); \
+    } else                                                                                                          \
+        AK(abub_posttrig_dev(slab, mu, sigma6, jobs, njobs, W, H, hist, nullptr, nullptr))
+        K3_CALL();
         CK(hipDeviceSynchronize());
         best = 1e30f;
         sum = 0;
         for (int r = 0; r < reps; r++) {
             CK(hipEventRecord(a, 0));
-            AK(abub_posttrig_dev(slab, mu, sigma6, jobs, njobs, W, H, hist, nullptr, nullptr));
+            K3_CALL();
             CK(hipEventRecord(b, 0));
             CK(hipEventSynchronize(b));
             float ms;
@@ -108,8 +125,11 @@ int main(int argc, char **argv)
             if (ms < best)
                 best = ms;
         }
-        printf("{\"k3\": 1, \"frames\": %d, \"W\": %d, \"H\": %d, \"ms_avg\": %.4f, \"ms_min\": %.4f, \"us_per_frame\": %.4f, \"compulsory_GBps\": %.1f}\n",
-               njobs, W, H, sum / reps, best, 1e3 * sum / reps / njobs, (double)P * njobs / (sum / reps * 1e-3) / 1e9);
+        uint32_t npairs = 0;
+        if (co)
+            CK(hipMemcpy(&npairs, pcount, 4, hipMemcpyDeviceToHost));
+        printf("{\"k3\": 1, \"compact\": %d, \"pairs\": %u, \"frames\": %d, \"W\": %d, \"H\": %d, \"ms_avg\": %.4f, \"ms_min\": %.4f, \"us_per_frame\": %.4f, \"compulsory_GBps\": %.1f}\n",
+               co, npairs, njobs, W, H, sum / reps, best, 1e3 * sum / reps / njobs, (double)P * njobs / (sum / reps * 1e-3) / 1e9);
         return 0;
     }
     std::vector<uint32_t> hh((size_t)njobs * 256);
