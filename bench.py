@@ -360,8 +360,8 @@ def main():
                 traffic_src = os.path.relpath(cand, ROOT)
                 break
     out["roofline"] = {
-        "kernel": "K2 trigger-only pass (the pipeline's stage 1) = k2_bound_chain (dominant) + k2_exact_groups + k2_rows on "
-                  "handed-over rows + k_hist_bin0, timed together with HIP events on the launch stream: fused ProcessFrame + "
+        "kernel": "K2 trigger-only pass (the pipeline's stage 1) = k2_bound_chain (dominant: bound scan + the waves' own "
+                  "exact tails) + k2_rows on handed-over rows + k_hist_bin0, timed together with HIP events on the launch stream: fused ProcessFrame + "
                   "256-bin histogram of every frame pair of the run",
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
