@@ -13,7 +13,7 @@ rc=$?
 for f in $(find $OUT -name '*kernel_stats.csv'); do cp $f $R/gpurun_out/$TAG/kernel_stats.csv; done
 for f in $(find $OUT -name '*kernel_trace.csv'); do
   head -1 $f > $R/gpurun_out/$TAG/kernel_trace_abub.csv
-  grep -E 'k2_|k1_|k3_|k4_|k_hist|k_fill|k_sigma|k1b' $f | tail -400 >> $R/gpurun_out/$TAG/kernel_trace_abub.csv
+  grep -E 'k2_|k1_|k3_|sus_|k4_|k_hist|k_fill|k_sigma|k1b' $f | tail -400 >> $R/gpurun_out/$TAG/kernel_trace_abub.csv
 done
 tail -1 $R/gpurun_out/$TAG/bench.log
 exit $rc

@@ -10,7 +10,7 @@ TAG=$1; shift
 O=$R/gpurun_out/$TAG; mkdir -p $O
 ARGS="--steps 2 --warmup 1 --inflight 1 --micro-frames 0 --no-cpu-baseline --ingest-events 0 --stream-steps 0 --min-seconds 0 --latency-steps 0 $@"
 cd /tmp
-KPAT='k2_|k3_|k1_|k4_|k_hist|k_pairs|k_slot|k1b|k_sigma|k_fill'
+KPAT='k2_|k3_|sus_|k1_|k4_|k_hist|k_pairs|k_slot|k1b|k_sigma|k_fill'
 rm -rf /tmp/bp_trace
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bp_trace -- python3 $R/bench.py $ARGS > $O/trace_bench.log 2>&1 || { echo "kernel-trace pass failed"; tail -3 $O/trace_bench.log; exit 1; }
 for f in $(find /tmp/bp_trace -name '*kernel_stats.csv'); do head -1 $f > $O/kernel_stats.csv; grep -E "$KPAT" $f >> $O/kernel_stats.csv; done
@@ -19,7 +19,7 @@ grep '^{"metric' $O/trace_bench.log | tail -1 > $O/bench_line.json
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVES" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM"; do
   name=$(echo $pass | cut -d' ' -f1)
   rm -rf /tmp/bp_$name
-  timeout -k 10 400 rocprofv3 --pmc $pass --kernel-trace --kernel-include-regex "k2_|k3_|k_hist" --output-format csv -d /tmp/bp_$name -- python3 $R/bench.py $ARGS > $O/pmc_$name.log 2>&1 || { echo "pmc pass $name failed"; tail -3 $O/pmc_$name.log; continue; }
+  timeout -k 10 400 rocprofv3 --pmc $pass --kernel-trace --kernel-include-regex "k2_|k3_|sus_|k_hist" --output-format csv -d /tmp/bp_$name -- python3 $R/bench.py $ARGS > $O/pmc_$name.log 2>&1 || { echo "pmc pass $name failed"; tail -3 $O/pmc_$name.log; continue; }
   for f in $(find /tmp/bp_$name -name '*counter_collection.csv'); do
     head -1 $f > $O/pmc_$name.csv; grep -E "$KPAT" $f >> $O/pmc_$name.csv
   done
