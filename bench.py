@@ -513,6 +513,16 @@ def microbench(args, torch, hip, dev, W, H):
     finally:
         hip.k2_set_option("bound", 1)
     res["nonzero_pixels_per_frame"] = float((P - h_store[:, 0].double()).mean().item())
+    # for scale: what this chip's memory system gives a plain device-to-device copy of the frames into D (torch's copy
+    # kernel: one read + one write per byte, no arithmetic) -- the store mode above moves the same compulsory bytes
+    nb = min(njobs, D.shape[0]) * P
+    ms, mn = timeit(lambda: D.view(-1)[:nb].copy_(slab.view(-1)[:nb]))
+    res["plain_copy_same_bytes"] = {"ms": ms, "ms_min": mn, "read_plus_write_GBps": 2.0 * nb / (ms * 1e-3) / 1e9,
+                                    "frac_of_8TBps": 2.0 * nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                    "store_mode_vs_copy": (2.0 * P * njobs / (res["store_mode"]["ms_per_launch"] * 1e-3)) /
+                                                          (2.0 * nb / (ms * 1e-3)),
+                                    "note": "tools/rowload_bench.cpp (profiles/*/rowload.jsonl) holds the hand-written flat read "
+                                            "and copy kernels: 6.4 TB/s read, 4.9-5.2 TB/s read+write on this chip"}
     res["contract_algorithmic_GBps"] = {"store_mode_4P": 4.0 * P * njobs / (res["store_mode"]["ms_per_launch"] * 1e-3) / 1e9,
                                         "trigger_only_3P": 3.0 * P * njobs / (res["trigger_only"]["ms_per_launch"] * 1e-3) / 1e9}
     del slab, D

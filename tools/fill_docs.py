@@ -79,6 +79,30 @@ t.append(f"(PMC columns: `profiles/r02/*_pmc_summary.json`; the microbench PMC p
          f"against {b['roofline']['bytes_per_launch'] / 1e9:.1f} GB compulsory, `frac_of_traffic` "
          f"{b['roofline'].get('frac_of_traffic', 0):.2f}.  In the SURVEY accounting the bench pass moves "
          f"{ca['GBps'] / 1e3:.1f} TB/s — above the HBM peak, which is why it is not used as a fraction.)")
+# the chip's own streaming ceilings (hand-written flat kernels of tools/rowload_bench.cpp)
+flat_r, flat_c = [], []
+with open(os.path.join(PROF, "rowload.jsonl")) as f:
+    for line in f:
+        if not line.startswith("{"):
+            continue
+        d = json.loads(line)
+        if d.get("pattern") == "flat read":
+            flat_r.append(d["TBps"])
+        if d.get("pattern") == "flat copy":
+            flat_c.append(d["TBps_read_plus_write"])
+if flat_r and flat_c:
+    st = mb["store_mode"]["compulsory_GBps"] / 1e3
+    tr = mb["trigger_only"]["compulsory_GBps"] / 1e3
+    t.append("")
+    t.append(f"For scale — what the chip gives kernels that do nothing else (`profiles/r02/rowload.jsonl`, 2.6 GB): a flat "
+             f"16-byte-per-lane **read {max(flat_r):.2f} TB/s** ({max(flat_r) / 8:.2f} of the 8 TB/s peak), a flat **copy "
+             f"{max(flat_c):.2f} TB/s** read + write ({max(flat_c) / 8:.2f}).  Store mode moves its compulsory bytes at "
+             f"{st:.2f} TB/s = **{st / max(flat_c):.2f} of the plain copy**; the trigger-only scan reads at {tr:.2f} TB/s = "
+             f"{tr / max(flat_r):.2f} of the flat read.")
+    pc = mb.get("plain_copy_same_bytes")
+    if pc:
+        t.append(f"(bench.py times torch's own device-to-device copy of the same bytes next to the store mode: "
+                 f"{pc['read_plus_write_GBps'] / 1e3:.2f} TB/s, store mode = {pc['store_mode_vs_copy']:.2f} of it.)")
 out["ROOFLINE_TABLE"] = "\n".join(t)
 
 tm = b["config"]["timing"]

@@ -310,6 +310,27 @@ static void run(const uint8_t *slab, const uint8_t *sg, uint32_t *out, uint8_t *
            nchains4 * 4, ms, 1e3 * ms / (nchains4 * 4), P * nchains4 * 4 / ms / 1e9);
 }
 
+// The chip's own streaming ceilings, for scale: every lane reads (and, in the copy, writes) 16 contiguous bytes per
+// step, the grid strides over the whole slab -- no rows, no chunks, no reuse.
+__global__ __launch_bounds__(256) void rd_flat(const uint4 *__restrict__ src, size_t n16, uint32_t *__restrict__ out)
+{
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        const uint4 v = src[i];
+        acc.x ^= v.x;
+        acc.y ^= v.y;
+        acc.z ^= v.z;
+        acc.w ^= v.w;
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u)
+        out[0] = 1;
+}
+__global__ __launch_bounds__(256) void copy_flat(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+        dst[i] = src[i];
+}
+
 int main(int argc, char **argv)
 {
     const int F = argc > 1 ? atoi(argv[1]) : 2000, R = argc > 2 ? atoi(argv[2]) : 0;
@@ -335,6 +356,16 @@ int main(int argc, char **argv)
         OCCRUN(1, 2, 0) OCCRUN(1, 3, 0) OCCRUN(1, 4, 0) OCCRUN(1, 6, 0) OCCRUN(1, 8, 0)
         OCCRUN(0, 4, 2) OCCRUN(0, 4, 4) OCCRUN(0, 4, 6) OCCRUN(0, 4, 8) OCCRUN(0, 8, 4) OCCRUN(0, 8, 6)
         OCCRUN(1, 4, 4) OCCRUN(1, 4, 6)
+    }
+    {
+        const size_t n16 = (size_t)1280 * 1024 * F / 16;
+        for (int blocks : {2048, 8192, 32768}) {
+            float ms = timeit([&] { hipLaunchKernelGGL(rd_flat, dim3(blocks), dim3(256), 0, 0, (const uint4 *)slab, n16, out); }, 5);
+            printf("{\"pattern\": \"flat read\", \"blocks\": %d, \"GB\": %.2f, \"ms\": %.4f, \"TBps\": %.3f}\n", blocks, n16 * 16 / 1e9, ms, n16 * 16 / ms / 1e9);
+            ms = timeit([&] { hipLaunchKernelGGL(copy_flat, dim3(blocks), dim3(256), 0, 0, (const uint4 *)slab, (uint4 *)diff, n16); }, 5);
+            printf("{\"pattern\": \"flat copy\", \"blocks\": %d, \"GB_read\": %.2f, \"ms\": %.4f, \"TBps_read_plus_write\": %.3f}\n", blocks, n16 * 16 / 1e9, ms,
+                   2 * n16 * 16 / ms / 1e9);
+        }
     }
     if (argc > 3) return 0;
     run<1280, 0>(slab, sg, out, diff, F, 1024, R);
