@@ -9,7 +9,7 @@ ranks of itself, relays rank 0's line and exits with the worst return code; it n
 
 Workload at N=1 (BASELINE.json configs[1], SURVEY.md 8d "Config 2"): one synthetic 40l-19-like run,
 E events x cams {0,1} x F=41 frames of 1280x1024 u8, resident in HBM before the timed region.
-A "step" is one pass of the detect path over the whole run.  Steps are software-pipelined (--inflight, default 3:
+A "step" is one pass of the detect path over the whole run.  Steps are software-pipelined (--inflight, default 6:
 host.PipelineRing): the host stages of step k run while the GPU works on step k+1; all K steps of a block start
 and finish inside that block's timed region.  The K-step block (barrier + synchronize on both sides, max over
 ranks) is repeated until --min-seconds have been measured; `ms_per_step` / `value` are the MEDIAN block.
@@ -45,8 +45,11 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--threads", type=int, default=16, help="host threads of the per-event state machines")
-    ap.add_argument("--inflight", type=int, default=3,
-                    help="steps in flight at once (each on its own pipeline object and host thread)")
+    ap.add_argument("--inflight", type=int, default=6,
+                    help="steps in flight at once (each on its own pipeline object and host thread); measured on one MI355X: "
+                         "2 -> 2.46, 3 -> 2.59, 4 -> 2.65, 6 -> 2.76, 8 -> 2.79, 12 -> 2.58 M frames/s")
+    ap.add_argument("--pipe-threads", type=int, default=0,
+                    help="host threads per pipeline object in flight (0 = --threads, capped so that all ranks of the node together stay near 400)")
     ap.add_argument("--stream-steps", type=int, default=10,
                     help="runs streamed from pinned host memory, two in flight (BASELINE configs[4] on this GPU: PCIe-inclusive "
                          "rate, reported in config only; 0 = skip)")
@@ -168,7 +171,7 @@ def main():
             return []
 
         run_steps(args.warmup)
-        gen_s, nwarm, ninfl = 0.0, args.warmup, 1
+        gen_s, nwarm, ninfl, pipe_threads = 0.0, args.warmup, 1, 0
         fingerprint, pipes, pipe = [], [], None
     else:
         from autobub3hs_amd import hip, host, synth
@@ -203,7 +206,10 @@ def main():
         # pipeline k % N, so the host stages of one step (state machines, contours) overlap the GPU stages of the
         # next.  Every step is still a full pass over the same batch, and all K of them complete inside the block.
         ninfl = max(1, args.inflight)
-        ring = host.PipelineRing(ninfl, local, W, H, F, E, C, tss, nthreads=max(1, args.threads))
+        # host threads per pipeline object: --threads each (the host stages sit on every step's critical path: 16 -> 2.75,
+        # 8 -> 2.68, 5 -> 2.43 M frames/s at six steps in flight), but at most ~400 threads on the node over all ranks
+        pipe_threads = args.pipe_threads if args.pipe_threads > 0 else min(max(1, args.threads), max(4, (400 // max(1, world)) // ninfl))
+        ring = host.PipelineRing(ninfl, local, W, H, F, E, C, tss, nthreads=pipe_threads)
         pipes = ring.pipes
         pipe = pipes[0]
         stream = torch.cuda.current_stream().cuda_stream
@@ -263,7 +269,7 @@ def main():
                         "per step: trigger search over every frame, genesis localisation, <=10-frame tracking, per-bubble records",
             "events_per_gpu": E, "cams": C, "frames_per_stack": F, "width": W, "height": H,
             "parallelism": f"events dealt round-robin over {world} GPU(s) (event % N), no collective",
-            "host_threads": args.threads,
+            "host_threads": args.threads, "host_threads_per_pipeline": pipe_threads,
             "warmup_steps_run": nwarm,
             "steps_in_flight": ninfl,  # stage_ms below are wall times inside one step: with >1 in flight they include
                                        # queueing behind the other steps' kernels and no longer add up to ms_per_step

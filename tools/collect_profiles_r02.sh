@@ -9,7 +9,7 @@ timeout -k 10 600 python bench.py > $O/bench_default.json 2> $O/bench_default.er
 timeout -k 10 600 python bench.py --width 1680 --height 1050 --cpu-seconds 6 --micro-frames 4000 > $O/bench_1680x1050.json 2> $O/bench_1680.err; echo "bench1680 rc=$?"
 bash tools/prof_bench_pmc.sh r02/pmc_bench > $O/pmc_bench.log 2>&1; tail -1 $O/pmc_bench.log | cut -c1-400
 bash tools/prof_bench_pmc.sh r02/pmc_bench_1680 --width 1680 --height 1050 > $O/pmc_bench_1680.log 2>&1; tail -1 $O/pmc_bench_1680.log | cut -c1-400
-# default bench (3 steps in flight) kernel-trace stats
+# default bench (several steps in flight) kernel-trace stats
 cd /tmp; rm -rf /tmp/kt_def
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_def -- python3 $R/bench.py --steps 6 --warmup 3 --micro-frames 0 --no-cpu-baseline --ingest-events 0 --stream-steps 0 --min-seconds 0 --latency-steps 0 > $O/trace_default.log 2>&1
 for f in $(find /tmp/kt_def -name '*kernel_stats.csv'); do head -1 $f > $O/bench_inflight3_kernel_stats.csv; grep -E 'k2_|k3_|sus_|k1_|k4_|k_hist|k_pairs|k_slot|k1b|k_sigma|k_fill' $f >> $O/bench_inflight3_kernel_stats.csv; done

@@ -108,7 +108,7 @@ out["ROOFLINE_TABLE"] = "\n".join(t)
 tm = b["config"]["timing"]
 lat, latq = b["config"]["latency_one_step_at_a_time_ms"], q["config"]["latency_one_step_at_a_time_ms"]
 out["E2E_TEXT"] = (
-    f"**{b['value'] / 1e6:.2f} M frames/s** = {b['ms_per_step']:.2f} ms per step, three steps in flight (median of "
+    f"**{b['value'] / 1e6:.2f} M frames/s** = {b['ms_per_step']:.2f} ms per step, {b['config'].get('steps_in_flight', '?')} steps in flight (median of "
     f"{tm['blocks']} blocks of {tm['steps_per_block']} steps over {tm['timed_seconds']:.1f} s; min {tm['ms_per_step_min']:.2f}, max "
     f"{tm['ms_per_step_max']:.2f} ms); one step at a time: {lat['median']:.2f} ms (host stages exposed).  At 1680×1050: "
     f"{q['value'] / 1e6:.2f} M frames/s, {q['ms_per_step']:.2f} ms per step ({latq['median']:.2f} ms one at a time).")
@@ -141,7 +141,7 @@ tot /= nsteps
 top = sorted(per.items(), key=lambda kv: -kv[1])[:6]
 out["GPU_BREAKDOWN"] = (f"{tot / 1e3:.2f} ms of kernels per step — " +
                         ", ".join(f"`{k}` {v / 1e3:.2f} ms" for k, v in top if v > 20) +
-                        f" — against {b['ms_per_step']:.2f} ms per step with three steps in flight: kernels cover "
+                        f" — against {b['ms_per_step']:.2f} ms per step with {b['config'].get('steps_in_flight', '?')} steps in flight: kernels cover "
                         f"{100 * tot / 1e3 / b['ms_per_step']:.0f} % of the step time (launch gaps, the candidate-list copies and "
                         f"the host stages that the other steps in flight do not hide make up the rest).")
 
