@@ -114,6 +114,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(world_env or "1")
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries the ONE result line and nothing else: everything the libraries underneath print there (the host
+    # library mirrors the reference's printf progress lines, e.g. "Camera 0 training ... complete.") goes to stderr
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        import ctypes
+
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)  # C stdio buffers of the redirected period
+        except OSError:
+            pass
+        os.write(result_fd, (json.dumps(obj) + "\n").encode())
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
         sys.exit(2)
@@ -287,7 +302,7 @@ def main():
         out["data"] = "none (dry protocol rehearsal, no kernels)"
         out["config"]["dry"] = True
         if rank == 0:
-            print(json.dumps(out))
+            emit(out)
         if dist:
             dist.destroy_process_group()
         return
@@ -386,7 +401,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, np, torch, slab, mu_d, sg_d, hist_h, pipe, tss, S, F, C)
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if dist:
         dist.destroy_process_group()
 

@@ -43,3 +43,19 @@ def test_bench_single_rank_dry():
     assert p.returncode == 0, p.stderr[-2000:]
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["n_gpus"] == 1 and out["config"]["timing"]["blocks"] == 1
+
+
+def test_stdout_is_exactly_one_json_line():
+    """The driver reads ONE JSON line from stdout: bench.py moves everything else that lands on fd 1 (the host library's
+    printf progress lines) to stderr."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.splitlines()
+    assert len(lines) == 1 and json.loads(lines[0])["metric"]
