@@ -70,6 +70,27 @@ t.append(mrow("same slab, store mode, **row machine alone** (`bound = 0`: the de
 t.append(mrow("same slab, trigger-only, row machine alone", mb, "trigger_only_row_machine_only"))
 t.append(mrow(f"{mq['frames']}-frame 1680×1050 slab, store mode", mq, "store_mode"))
 t.append(mrow(f"{mq['frames']}-frame 1680×1050 slab, trigger-only", mq, "trigger_only", pm["k2_hist_1680"]))
+# K3: the tracking frames' launch of the run pipeline (scan + suspect-list tail + handed-over pieces), one step in flight
+def k3_row(label, statsfile, p, W, H):
+    k3 = p.get("k3")
+    if not k3:
+        return None
+    us = 0.0
+    for n, r in stats(statsfile).items():
+        sn = short(n)
+        if sn.startswith("k3_") or sn.startswith("sus_tail_list<3"):
+            us += float(r["AverageNs"]) / 1e3
+    nfr = k3["tracking_frames_per_launch_at_most"]
+    gbps = nfr * W * H / (us * 1e-6) / 1e9
+    return (f"| {label} | {us / 1e3:.2f} ms / {nfr} frames | {us / nfr:.3f} | {gbps / 8000:.3f} | "
+            f"{k3['hbm_bytes_per_frame_over_WH']:.2f}·W·H | {k3['scan_valu_insts_per_pixel']:.1f} |")
+
+
+for row in (k3_row("bench default, K3 over the tracking frames (`k3_bound_scan<5,5>` + `sus_tail_list<3>` + pieces; compulsory 1·W·H per frame)",
+                   "bench_inflight1_kernel_stats.csv", bp, 1280, 1024),
+            k3_row("bench 1680×1050, K3 (`k3_bound_scan<7,4>` + tail + pieces)", "bench_1680x1050_inflight1_kernel_stats.csv", qp, 1680, 1050)):
+    if row:
+        t.append(row)
 ca = b["roofline"]["contract_algorithmic"]
 t.append("")
 t.append(f"(PMC columns: `profiles/r02/*_pmc_summary.json`; the microbench PMC passes ran the native `tools/k2_microbench` on 2000 "

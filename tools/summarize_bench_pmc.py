@@ -64,6 +64,25 @@ def main(d, out):
         "corrections": "FETCH_SIZE KiB x2 (gfx950 wide streaming reads), WRITE_SIZE KiB x1; separate --pmc passes",
         "bench_line_of_the_trace_pass": {k: line[k] for k in ("value", "ms_per_step")} | {"roofline_ms_per_launch": line["roofline"]["ms_per_launch"]},
     }
+    # K3 (the tracking frames of the triggered stacks): scan + suspect-list tail + handed-over pieces, per dispatch
+    k3k = [k for k in per.get("FETCH_SIZE", {}) if k.startswith("k3_") or k.startswith("sus_tail_list<3")]
+    if k3k:
+        k3 = {kn: {c: mean(c, kn, None) for c in per} for kn in k3k}
+        for kn in k3k:
+            k3[kn].update(meta.get(kn, {}))
+        nfr = 10 * int(line["config"].get("triggered_stacks", 0))  # <= 10 tracking frames per triggered stack
+        f3 = sum(v.get("FETCH_SIZE", 0) for v in k3.values()) * 1024 * 2
+        w3 = sum(v.get("WRITE_SIZE", 0) for v in k3.values()) * 1024
+        scan3 = [k for k in k3k if k.startswith("k3_bound_scan")]
+        res["k3"] = {
+            "kernels": sorted(k3k), "tracking_frames_per_launch_at_most": nfr,
+            "hbm_bytes_per_launch": f3 + w3,
+            "hbm_bytes_per_frame_over_WH": (f3 + w3) / max(1, nfr) / P,
+            "l2_hit_rate": sum(v.get("TCC_HIT_sum", 0) for v in k3.values()) /
+                           max(1.0, sum(v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0) for v in k3.values())),
+            "scan_valu_insts_per_pixel": (k3[scan3[0]].get("SQ_INSTS_VALU", 0) * 64 / max(1, nfr * P)) if scan3 else None,
+            "by_kernel": k3,
+        }
     # kernel durations of the trace pass (no counters): the pass's kernels at full grid
     st = os.path.join(d, "kernel_trace_abub.csv")
     if os.path.exists(st):
