@@ -1612,6 +1612,13 @@ static int diff_hist_impl(const uint8_t *frames, const uint8_t *sigma6, const ab
             int nch = 8;
             if ((long long)njobs * nch < 8192)
                 nch = (8192 + njobs - 1) / njobs;
+            static int k2chunks = -1;
+            if (k2chunks < 0) {
+                const char *e = getenv("ABUB_K2_CHUNKS"); // tuning knob: chunks per frame (0 = automatic)
+                k2chunks = e ? atoi(e) : 0;
+            }
+            if (k2chunks > 0)
+                nch = k2chunks;
             nch = (nch + 7) / 8 * 8; // keep chunk id == XCD id
             R = (H + nch - 1) / nch;
             if (R < 16)
