@@ -12,7 +12,7 @@ bash tools/prof_bench_pmc.sh r02/pmc_bench_1680 --width 1680 --height 1050 > $O/
 # default bench (several steps in flight) kernel-trace stats
 cd /tmp; rm -rf /tmp/kt_def
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_def -- python3 $R/bench.py --steps 6 --warmup 3 --micro-frames 0 --no-cpu-baseline --ingest-events 0 --stream-steps 0 --min-seconds 0 --latency-steps 0 > $O/trace_default.log 2>&1
-for f in $(find /tmp/kt_def -name '*kernel_stats.csv'); do head -1 $f > $O/bench_inflight3_kernel_stats.csv; grep -E 'k2_|k3_|sus_|k1_|k4_|k_hist|k_pairs|k_slot|k1b|k_sigma|k_fill' $f >> $O/bench_inflight3_kernel_stats.csv; done
+for f in $(find /tmp/kt_def -name '*kernel_stats.csv'); do head -1 $f > $O/bench_default_kernel_stats.csv; grep -E 'k2_|k3_|sus_|k1_|k4_|k_hist|k_pairs|k_slot|k1b|k_sigma|k_fill' $f >> $O/bench_default_kernel_stats.csv; done
 cd $R
 # native microbench (BASELINE configs[2] kernel) with counters: trigger-only, store, store through the row machine alone
 bash tools/prof_k2.sh r02/k2_hist 2000 0 > $O/prof_k2_hist.log 2>&1; python3 tools/summarize_pmc.py gpurun_out/r02/k2_hist $O/k2_hist_pmc_summary.json

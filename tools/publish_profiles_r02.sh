@@ -2,7 +2,7 @@
 # copies the summaries of tools/collect_profiles_r02.sh (gpurun_out/r02/, scratch) into profiles/r02/ (tracked)
 set -e
 S=gpurun_out/r02; D=profiles/r02; mkdir -p $D
-cp $S/bench_default.json $S/bench_1680x1050.json $S/bench_inflight3_kernel_stats.csv $S/k2_hist_pmc_summary.json $S/k2_store_pmc_summary.json \
+cp $S/bench_default.json $S/bench_1680x1050.json $S/bench_default_kernel_stats.csv $S/k2_hist_pmc_summary.json $S/k2_store_pmc_summary.json \
    $S/k2_store_rowmachine_pmc_summary.json $S/k2_hist_1680_pmc_summary.json $S/valu_rate.jsonl $S/rowload.jsonl $D/
 cp $S/pmc_bench/bench_pmc_summary.json $D/bench_pmc_summary.json
 cp $S/pmc_bench/kernel_stats.csv $D/bench_inflight1_kernel_stats.csv
