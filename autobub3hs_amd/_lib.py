@@ -19,7 +19,7 @@ class Job(C.Structure):
 def build(force=False):
     """Compile the HIP library for gfx950 (cross-compiles without a GPU)."""
     srcs = [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))
-            if f.endswith((".hip", ".h"))] + [HEADER]
+            if f.endswith((".hip", ".h", ".hpp")) or f == "Makefile"] + [HEADER]
     stale = force or not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", os.path.join(HERE, "csrc"), "-s"])

@@ -1,6 +1,6 @@
 // abub_ctx.hip -- layer (B) of include/abub_hip.h: a per-host-thread context that owns the HBM slabs
 // of one (event, camera) at a time and moves host buffers in and out.  Everything here is plumbing
-// around the launchers of abub_kernels.hip; no pixel arithmetic happens on the host.
+// around the launchers of abub_k2.hip / abub_k3.hip / abub_misc.hip; no pixel arithmetic happens on the host.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -31,7 +31,7 @@ struct abub_ctx {
     int have_model;
 };
 
-int abub_set_err_(int code, const char *what, hipError_t e); // abub_kernels.hip: text for abub_last_error()
+int abub_set_err_(int code, const char *what, hipError_t e); // abub_misc.hip: text for abub_last_error()
 static int cfail(int code, const char *what, hipError_t e = hipSuccess) { return abub_set_err_(code, what, e); }
 #define CCHK(x)                                  \
     do {                                         \

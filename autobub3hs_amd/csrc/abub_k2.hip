@@ -1,0 +1,1269 @@
+// abub_k2.hip -- K2: fused AnalyzerUnit::ProcessFrame + 256-bin histogram (gfx950, wave64, no MFMA) and its stateless
+// C-ABI launchers (include/abub_hip.h).  Kernel inventory: DESIGN.md section "Kernels".
+//   k2_rows<NDW,STORE,PF,COMPACT>  register-rolling row machine (optional stored image / fused candidate list; list mode
+//                                  for handed-over rows)
+//   k2_bound_chain / k2_bound_scan bound-and-verify: proves rows of D zero from a bound, lists the rest
+//   k2_generic                     same arithmetic, any size / ROI, LDS tile (also the ROI overload)
+#include "abub_dev.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// K2 fast: register-rolling rows.
+//
+// One wave (64-thread workgroup) owns output rows [y0,y1) of one job.  Lane L holds 4*NDW consecutive
+// pixels of a row (blocked mapping), the wave spans the whole row: W == 4*NDW*nl, nl <= 64 lanes.
+// Per input row: 3*NDW dword loads/lane (cur, ref, sigma6) -> saturating differences on u16 pairs
+// (two pixels per 32-bit register, pos plane and neg plane) -> horizontal 1-4-6-4-1 with the two
+// neighbour pairs fetched from the adjacent lanes by DPP wave shifts (reflect-101 in-lane at the
+// image edges) -> vertical 1-4-6-4-1 as four in-place accumulators per pair (no ring rotation)
+// -> (S+128)>>8 via byte permute, |pos-neg|, LDS histogram of the (rare) non-zero pixels, optional store.
+// Every u16 lane stays < 65536: H <= 4080+8, V <= 16*4088 = 65408.
+// ------------------------------------------------------------------------------------------------
+// persistent per-wave state of the vertical pass: four in-place accumulators per u16 pair and plane
+// out = a0 + X ; a0 = a1 + 4X ; a1 = a2 + 6X ; a2 = Xprev + 4X.  The previous row's X lives in a second
+// register set that alternates with the current one (K2Row), so nothing is copied at the loop back-edge.
+template <int NDW>
+struct K2Acc {
+    uint32_t pa0[2 * NDW], pa1[2 * NDW], pa2[2 * NDW];
+    uint32_t na0[2 * NDW], na1[2 * NDW], na2[2 * NDW];
+};
+template <int NDW>
+struct K2Row {
+    uint32_t hp[2 * NDW], hn[2 * NDW]; // horizontally filtered row, both planes
+};
+
+// pos / neg planes of one row as u16 pairs (AnalyzerUnit.cpp:351-352)
+template <int NDW>
+__device__ __forceinline__ void k2_planes(const RowIn<NDW> &in, uint32_t (&Xp)[2 * NDW], uint32_t (&Xn)[2 * NDW])
+{
+#pragma unroll
+    for (int d = 0; d < NDW; d++) {
+        uint32_t c0 = widen_lo(in.c[d]), c1 = widen_hi(in.c[d]);
+        uint32_t r0 = widen_lo(in.r[d]), r1 = widen_hi(in.r[d]);
+        uint32_t s0 = widen_lo(in.s[d]), s1 = widen_hi(in.s[d]);
+        Xp[2 * d] = pk_subsat(c0, r0 + s0);
+        Xn[2 * d] = pk_subsat(r0, c0 + s0);
+        Xp[2 * d + 1] = pk_subsat(c1, r1 + s1);
+        Xn[2 * d + 1] = pk_subsat(r1, c1 + s1);
+    }
+}
+// horizontal 1-4-6-4-1 of one row, both planes (AnalyzerUnit.cpp:359-360; the +128 rounding is applied at the end)
+template <int NDW>
+__device__ __forceinline__ void k2_hpass(const uint32_t (&Xp)[2 * NDW], const uint32_t (&Xn)[2 * NDW], bool first_lane,
+                                         bool last_lane, uint32_t (&Hp)[2 * NDW], uint32_t (&Hn)[2 * NDW])
+{
+    constexpr int NP = 2 * NDW;
+    // left pair (p[-2],p[-1]) and right pair (p[n],p[n+1]): neighbour lanes, reflect-101 at the edges
+    uint32_t reflLp = __builtin_amdgcn_perm(Xp[0], Xp[1], 0x07060100u); // (X1.lo, X0.hi) = (p2,p1)
+    uint32_t reflLn = __builtin_amdgcn_perm(Xn[0], Xn[1], 0x07060100u);
+    uint32_t reflRp = __builtin_amdgcn_perm(Xp[NP - 2], Xp[NP - 1], 0x07060100u); // (p[n-2],p[n-3])
+    uint32_t reflRn = __builtin_amdgcn_perm(Xn[NP - 2], Xn[NP - 1], 0x07060100u);
+    uint32_t Lp = __builtin_amdgcn_update_dpp(0u, Xp[NP - 1], DPP_WAVE_SHR1, 0xf, 0xf, false);
+    uint32_t Ln = __builtin_amdgcn_update_dpp(0u, Xn[NP - 1], DPP_WAVE_SHR1, 0xf, 0xf, false);
+    uint32_t Rp = __builtin_amdgcn_update_dpp(0u, Xp[0], DPP_WAVE_SHL1, 0xf, 0xf, false);
+    uint32_t Rn = __builtin_amdgcn_update_dpp(0u, Xn[0], DPP_WAVE_SHL1, 0xf, 0xf, false);
+    Lp = first_lane ? reflLp : Lp;
+    Ln = first_lane ? reflLn : Ln;
+    Rp = last_lane ? reflRp : Rp;
+    Rn = last_lane ? reflRn : Rn;
+    uint32_t am1p = __builtin_amdgcn_alignbit(Xp[0], Lp, 16); // (p[-1], p[0])
+    uint32_t am1n = __builtin_amdgcn_alignbit(Xn[0], Ln, 16);
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        uint32_t xm1p = j ? Xp[j - 1] : Lp, xp1p = j + 1 < NP ? Xp[j + 1] : Rp;
+        uint32_t xm1n = j ? Xn[j - 1] : Ln, xp1n = j + 1 < NP ? Xn[j + 1] : Rn;
+        uint32_t ap1p = __builtin_amdgcn_alignbit(xp1p, Xp[j], 16); // (p[2j+1], p[2j+2])
+        uint32_t ap1n = __builtin_amdgcn_alignbit(xp1n, Xn[j], 16);
+        uint32_t sp = am1p + ap1p, sn = am1n + ap1n;
+        uint32_t tp = xm1p + xp1p, tn = xm1n + xp1n;
+        Hp[j] = pk_madk<6>(Xp[j], (sp << 2) + tp); // every u16 lane <= 4080
+        Hn[j] = pk_madk<6>(Xn[j], (sn << 2) + tn);
+        am1p = ap1p;
+        am1n = ap1n;
+    }
+}
+
+// one input row -> one output row (valid once 5 rows went in)
+template <int NDW, bool STORE, bool COMPACT>
+__device__ __forceinline__ void k2_row(const RowIn<NDW> &in, K2Acc<NDW> &A, K2Row<NDW> &Hcur,
+                                       const K2Row<NDW> &Hprev, bool emit, bool active,
+                                       bool first_lane, bool last_lane, uint32_t *lh,
+                                       uint32_t *__restrict__ po, const Compact &cp, uint32_t pix0, int &zrun)
+{
+    constexpr int NP = 2 * NDW;
+    // sat(sat(c - r) - s) == sat(c - (r + s)) for s >= 0, and r + s <= 510 fits the u16 lane: one plain
+    // 32-bit add (VOP2) + one saturating packed subtract per plane instead of two packed subtracts
+    uint32_t Xp[NP], Xn[NP];
+    k2_planes<NDW>(in, Xp, Xn);
+
+    // ---- zero-run shortcut (wave-uniform) ------------------------------------------------------
+    // A row whose pos and neg planes vanish on every lane filters to H = 0, and after four such rows the
+    // whole vertical state (a0,a1,a2 and both H sets) is zero: further zero rows leave it untouched and emit
+    // D = 0, so everything below is skipped.  Static-camera frames spend most of their rows here.
+    {
+        uint32_t nz = 0;
+#pragma unroll
+        for (int j = 0; j < NP; j++)
+            nz |= Xp[j] | Xn[j];
+        const bool rowzero = __builtin_amdgcn_ballot_w64(nz != 0) == 0;
+        if (rowzero && zrun >= 4) {
+            if (STORE && emit && active) {
+#pragma unroll
+                for (int d = 0; d < NDW; d++)
+                    po[d] = 0;
+            }
+            return;
+        }
+        zrun = rowzero ? zrun + 1 : 0;
+    }
+
+    // ---- horizontal 1-4-6-4-1 (AnalyzerUnit.cpp:359-360; the +128 rounding is applied at the end) ----
+    uint32_t(&Hp)[NP] = Hcur.hp;
+    uint32_t(&Hn)[NP] = Hcur.hn;
+    k2_hpass<NDW>(Xp, Xn, first_lane, last_lane, Hp, Hn);
+
+    // ---- vertical 1-4-6-4-1, (S+128)>>8, absdiff (AnalyzerUnit.cpp:370) -----------------------
+    uint32_t Vp[NP], Vn[NP];
+    uint32_t big = 0; // OR of all sums S: if no u16 lane reaches 128 every (S+128)>>8, hence D, is 0
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        Vp[j] = A.pa0[j] + Hp[j];
+        Vn[j] = A.na0[j] + Hn[j];
+        const uint32_t p4 = Hp[j] << 2, n4 = Hn[j] << 2; // shared by a0 and a2 (plain VOP2 shift + adds)
+        A.pa0[j] = A.pa1[j] + p4;
+        A.na0[j] = A.na1[j] + n4;
+        A.pa1[j] = pk_madk<6>(Hp[j], A.pa2[j]);
+        A.na1[j] = pk_madk<6>(Hn[j], A.na2[j]);
+        A.pa2[j] = Hprev.hp[j] + p4;
+        A.na2[j] = Hprev.hn[j] + n4;
+        big |= Vp[j] | Vn[j];
+    }
+    uint32_t Dp[NP];
+    uint32_t any = 0;
+    // wave-uniform shortcut: for almost every row of almost every frame all sums stay below 128
+    const bool quiet = __builtin_amdgcn_ballot_w64((big & 0xff80ff80u) != 0) == 0;
+    if (quiet) {
+#pragma unroll
+        for (int j = 0; j < NP; j++)
+            Dp[j] = 0;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            // (S+128)>>8: byte1 / byte3 of the u16 lanes after the rounding add (S <= 65280: no lane overflow)
+            uint32_t rp = __builtin_amdgcn_perm(0u, Vp[j] + 0x00800080u, 0x0c030c01u);
+            uint32_t rn = __builtin_amdgcn_perm(0u, Vn[j] + 0x00800080u, 0x0c030c01u);
+            Dp[j] = pk_absdiff(rp, rn);
+            any |= Dp[j];
+        }
+    }
+
+    if (emit) {
+        const bool mine = any && active;
+        if (__builtin_amdgcn_ballot_w64(mine)) { // rare and wave-uniform: D is zero for almost every pixel
+            uint32_t pos = 0;
+            if (COMPACT) {
+                uint32_t c = 0;
+                if (mine) {
+#pragma unroll
+                    for (int j = 0; j < NP; j++)
+                        c += ((int)(Dp[j] & 0xffffu) > cp.thr) + ((int)(Dp[j] >> 16) > cp.thr);
+                }
+                pos = compact_reserve(cp, c);
+            }
+            if (mine) {
+#pragma unroll
+                for (int j = 0; j < NP; j++) {
+                    uint32_t lo = Dp[j] & 0xffffu, hi = Dp[j] >> 16;
+                    if (lo) {
+                        atomicAdd(&lh[lo], 1u);
+                        if (COMPACT)
+                            compact_put(cp, pos, lo, pix0 + 2 * j);
+                    }
+                    if (hi) {
+                        atomicAdd(&lh[hi], 1u);
+                        if (COMPACT)
+                            compact_put(cp, pos, hi, pix0 + 2 * j + 1);
+                    }
+                }
+            }
+        }
+        if (STORE && active) {
+#pragma unroll
+            for (int d = 0; d < NDW; d++)
+                po[d] = __builtin_amdgcn_perm(Dp[2 * d + 1], Dp[2 * d], 0x06040200u);
+        }
+    }
+}
+
+#ifndef K2_WAVES_PER_EU
+#define K2_WAVES_PER_EU 1
+#endif
+template <int NDW, bool STORE, int PF, bool COMPACT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER_EU))) void k2_rows(const uint8_t *__restrict__ frames,
+                                              const uint8_t *__restrict__ sigma6,
+                                              const abub_job *__restrict__ jobs, int W, int H,
+                                              int rows_per_chunk, int nchunks,
+                                              uint32_t *__restrict__ hist, uint8_t *__restrict__ diff,
+                                              const int32_t *__restrict__ cthr, uint32_t *pairs,
+                                              uint32_t pcap, uint32_t *pcount, uint32_t slot_base,
+                                              const uint2 *__restrict__ unit_list,
+                                              const uint32_t *__restrict__ unit_count)
+{
+    constexpr int NP = 2 * NDW; // u16-pair registers per plane per lane
+    __shared__ uint32_t lh[256];
+
+    const int lane = threadIdx.x;
+    // list mode (bound-and-verify hand-over): the grid strides over the listed units; otherwise unit = block
+    const uint32_t nunits_ = unit_list ? *unit_count : gridDim.x;
+    for (uint32_t ui = blockIdx.x; ui < nunits_; ui += gridDim.x) {
+    const int unit = unit_list ? (int)unit_list[ui].x : (int)ui;
+    const int job = unit / nchunks;
+    const int chunk = unit - job * nchunks; // chunk fastest: unit % 8 == chunk % 8 when nchunks % 8 == 0
+    const abub_job jb = jobs[job];
+    const size_t P = (size_t)W * H;
+    const uint8_t *cur = frames + (size_t)jb.cur * P;
+    const uint8_t *ref = frames + (size_t)jb.ref * P;
+    const uint8_t *sg = sigma6 + (size_t)jb.model * P;
+    const int nl = W / (4 * NDW);
+    const bool active = lane < nl;
+    const bool first_lane = lane == 0;
+    const bool last_lane = lane == nl - 1;
+    const int xoff = active ? lane * 4 * NDW : 0; // idle lanes shadow lane 0 (results unused)
+
+    // list mode: a handed-over piece, rows [y & 0xffff, y >> 16)
+    const int y0 = unit_list ? (int)(unit_list[ui].y & 0xffffu) : chunk * rows_per_chunk;
+    int y1 = unit_list ? (int)(unit_list[ui].y >> 16) : (chunk + 1) * rows_per_chunk;
+    if (y1 > H)
+        y1 = H;
+    const int T = y1 - y0 + 4; // input rows y0-2 .. y1+1 (reflected)
+
+    lh[lane] = 0;
+    lh[lane + 64] = 0;
+    lh[lane + 128] = 0;
+    lh[lane + 192] = 0;
+    __syncthreads();
+
+    K2Acc<NDW> A;
+#pragma unroll
+    for (int j = 0; j < NP; j++)
+        A.pa0[j] = A.pa1[j] = A.pa2[j] = A.na0[j] = A.na1[j] = A.na2[j] = 0;
+    K2Row<NDW> HR[2];
+#pragma unroll
+    for (int j = 0; j < NP; j++)
+        HR[0].hp[j] = HR[0].hn[j] = HR[1].hp[j] = HR[1].hn[j] = 0;
+
+    uint8_t *dbase = STORE ? diff + (size_t)jb.out * P + xoff : nullptr;
+    Compact cp;
+    cp.pairs = COMPACT ? pairs : nullptr;
+    cp.count = pcount;
+    cp.cap = pcap;
+    cp.slot = jb.out + slot_base;
+    cp.thr = COMPACT ? cthr[jb.out] : 255;
+
+    // Software prefetch PF rows ahead through a ring of PF+1 row buffers.  The loop is unrolled by
+    // U = lcm(PF+1, 2) so that ring slots are compile-time registers and neither the ring nor the
+    // vertical accumulators (ping-pong period 2) need register moves at the back-edge.
+    constexpr int RING = PF + 1;
+    constexpr int U = (RING % 2 == 0) ? RING : 2 * RING;
+    RowIn<NDW> ring[RING];
+#pragma unroll
+    for (int k = 0; k < PF; k++) {
+        int tk = k < T ? k : T - 1;
+        k2_load_row<NDW>(ring[k], cur, ref, sg, reflect101(y0 - 2 + tk, H), W, xoff);
+    }
+    // T is rounded up to a multiple of U: the (at most U-1) extra rows re-read the last input row and emit
+    // nothing, which keeps the unrolled body free of guards (no phi copies of the ring / accumulators)
+    const int Tpad = (T + U - 1) / U * U;
+    int zrun = 4; // the vertical state starts out all zero
+    for (int t = 0; t < Tpad; t += U) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int tt = t + u;
+            int tn = tt + PF < T ? tt + PF : T - 1;
+            k2_load_row<NDW>(ring[(u + PF) % RING], cur, ref, sg, reflect101(y0 - 2 + tn, H), W, xoff);
+            int y = y0 + tt - 4;
+            k2_row<NDW, STORE, COMPACT>(ring[u % RING], A, HR[u & 1], HR[(u & 1) ^ 1], tt >= 4 && tt < T, active,
+                                        first_lane, last_lane, lh,
+                                        reinterpret_cast<uint32_t *>(dbase + (ptrdiff_t)y * W), cp,
+                                        (uint32_t)(y * W + xoff), zrun);
+        }
+    }
+
+    __syncthreads();
+    uint32_t *gh = hist + (size_t)jb.out * 256;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t v = lh[lane + 64 * k];
+        if (v && (lane + 64 * k))
+            atomicAdd(&gh[lane + 64 * k], v);
+    }
+    __syncthreads(); // lh is zeroed again by the next unit
+    } // units
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 "bound and verify".  D(y,x) != 0 needs a 5x5 weighted sum S >= 128 in one plane.  With X = pos + neg (disjoint
+// supports, so both plane sums are <= the sum over X) and the lane's pixels in groups of four columns:
+//     S(y,x) <= sum_i w_i * 6 * M_g(y+i),   M_g(r) = m_{g-1}(r) + m_g(r) + m_{g+1}(r),   m_g = mass of X in group g
+// (every tap of the horizontal filter is <= 6 and reaches at most the neighbouring group; at the image edges the
+// reflected columns fall into the edge group itself, which the edge-replicated m_{-1} = m_0 counts a second time).
+//   k2_bound_scan / k2_bound_chain
+//       one wave per (job, chunk) -- or per K chained jobs -- carries only this bound down the rows: the same
+//       1-4-6-4-1 recurrence, but on packed group masses instead of 4*NDW filtered pairs in two planes, and proves
+//       "D is zero" for whole rows with one ballot.  Groups it cannot prove are remembered in LDS (at most K2B_PEND
+//       per job and chunk) and computed exactly BY THE SAME WAVE once its scan is over (k2b_tail: the four pixels
+//       straight from the definition, one lane per group) -- no list in global memory, no second kernel.  A chunk
+//       whose rows keep exceeding 32 suspects (one row of the row machine costs about 30 exact groups), or that
+//       would overflow its LDS list, hands its REMAINING rows over.  (Handing over only the next K2B_SUB rows and
+//       scanning on behind them was measured equal in time and cost a wave of occupancy at W = 1680.)
+//   k2_rows (list mode)
+//       the full row machine on the handed-over row ranges, cut into pieces of K2B_SUB rows so that the few of them
+//       spread over the chip instead of serialising behind one wave each.
+// Store mode: the scan writes the rows it is responsible for as zeros, the tail overwrites its groups' dwords (same
+// wave, later in program order), the row machine writes the handed-over rows.
+// Every pixel is either proven zero or computed with the reference arithmetic, never twice: histograms and D are
+// bit-identical to the plain k2_rows pass.
+// Packed halves: a register holds (mass of columns 0,2 | mass of columns 1,3) of a group; all recurrences are linear
+// and stay < 65536 per half (<= 16 * 4 * 2 * 255 with paired groups); the row test folds max-of-halves over the
+// lane's groups, which can only over-estimate, the per-group test on a suspicious row folds exactly.
+// ------------------------------------------------------------------------------------------------
+
+// Lane -> pixel mapping of the scan kernels.  A row is cut into segments; in segment s every active lane owns segK(s)
+// consecutive dwords (4-pixel groups): lane L the groups [gbase[s] + segK(s) * L, + segK(s)).
+//   blocked (SPLIT = false): one segment of NDW dwords per lane -- the row machine's mapping; a lane's dwordx4 + dword
+//                            loads then sit at a 4 * NDW byte stride, so every load instruction touches every line
+//                            of the row partially;
+//   split   (SPLIT = true):  two segments of 4 and NDW - 4 dwords per lane (NDW = 5 .. 7) over the same nl = W / (4 NDW)
+//                            lanes: the first 16 * nl bytes of the row go out as one dwordx4 per lane, the rest as one
+//                            dword / dwordx2 / dwordx3 per lane -- each load instruction covers ONE contiguous span of
+//                            the row with whole pieces per lane.  tools/rowload_bench.cpp: the chained scan's access
+//                            pattern is 3 % cheaper at W = 1280 and 12 % at W = 1680 this way.
+// The suspect codes are global group indices and hand-overs are row ranges, so the row machine (always blocked) and
+// the exact tails do not care which mapping the scan used.
+template <int NDW, bool SPLIT>
+struct ScanMap {
+    static_assert(!SPLIT || (NDW >= 5 && NDW <= 7), "the split mapping is a dwordx4 plus 1 .. 3 dwords per lane");
+    static constexpr int NSEG = SPLIT ? 2 : 1;
+    static __device__ __host__ constexpr int segK(int s) { return !SPLIT ? NDW : (s == 0 ? 4 : NDW - 4); }
+    static __device__ __host__ constexpr int segD0(int s) { return !SPLIT ? 0 : (s == 0 ? 0 : 4); }
+    static __device__ __host__ constexpr int segOf(int d) { return !SPLIT ? 0 : (d < 4 ? 0 : 1); }
+    int nl;          // active lanes (the same in every segment)
+    int gbase[NSEG]; // first 4-pixel group of the segment
+    __device__ __forceinline__ void init(int W)
+    {
+        nl = W / (4 * NDW);
+#pragma unroll
+        for (int s = 0; s < NSEG; s++)
+            gbase[s] = nl * segD0(s);
+    }
+    // byte offset of the lane's piece of segment s in a row (idle lanes shadow lane 0: valid address, results unused)
+    __device__ __forceinline__ int byteoff(int s, int lane) const { return 4 * (gbase[s] + segK(s) * (lane < nl ? lane : 0)); }
+    __device__ __forceinline__ void load(uint32_t (&r)[NDW], const uint8_t *__restrict__ row, int lane) const
+    {
+#pragma unroll
+        for (int s = 0; s < NSEG; s++) {
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(row + byteoff(s, lane));
+#pragma unroll
+            for (int d = 0; d < segK(s); d++)
+                r[segD0(s) + d] = p[d];
+        }
+    }
+    __device__ __forceinline__ void store_zero(uint8_t *__restrict__ row, int lane) const
+    {
+        if (lane < nl) {
+#pragma unroll
+            for (int s = 0; s < NSEG; s++) {
+                uint32_t *p = reinterpret_cast<uint32_t *>(row + byteoff(s, lane));
+#pragma unroll
+                for (int d = 0; d < segK(s); d++)
+                    p[d] = 0;
+            }
+        }
+    }
+};
+
+template <int NDW>
+struct K2BoundJob { // per-job state of the bound recurrence and of its suspect list (all wave-uniform but b*/Mprev)
+    // The recurrence runs on PAIRS of 4-pixel groups (8 columns, the last one alone when NDW is odd): the taps of a
+    // column still reach at most the neighbouring 4-pixel group on either side, so M = left group + own pair + right
+    // group bounds every column of the pair; suspects are listed as their 4-pixel groups.
+    static constexpr int GS = K2B_GS > NDW ? NDW : K2B_GS; // 4-pixel groups per recurrence group
+    static constexpr int NG = (NDW + GS - 1) / GS;
+    // vertical 1-4-6-4-1 of the group masses as four cascaded two-tap sums (binomial = (1 + z^-1)^4): per group four
+    // plain 32-bit adds and no shift / multiply; P[k][parity] = output of stage k at the previous row of that parity
+    // (the row loops are unrolled by two, so nothing is ever copied).  Wide rows (NDW >= 6) keep the state in four
+    // in-place accumulators instead (P[k][0]): 16 instead of 32 registers per job there, which is a wave of occupancy.
+    static constexpr bool CASCADE = NDW <= 5;
+    uint32_t P[4][2][NG];
+    uint32_t npend, hot, jidx;
+    int handover; // < 0: scanning; >= 0: first output row left to the row machine (or "nothing to do")
+};
+
+// one input row of one job: group masses m[] -> bound of output row y; suspects go to the job's LDS list.
+// Everything that steers control flow is read through SGPRs (ballots, s_bcnt1), so the scan loops compile to scalar
+// branches.
+template <int NDW, bool SPLIT>
+__device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const int par, uint32_t (&m)[NDW], bool emit, int y,
+                                        const ScanMap<NDW, SPLIT> &map, int lane, uint32_t ngroups, uint32_t budget,
+                                        uint32_t *pend, const SusList &gl)
+{
+    using Map = ScanMap<NDW, SPLIT>;
+    constexpr int NSEG = Map::NSEG;
+    // masses of the groups left of each segment's first and right of its last group: neighbour lanes inside a
+    // segment (DPP), the adjacent segment's end at lane 0 / the last active lane (one v_readlane), the replicated own
+    // edge group at the image border (the reflected column lies inside it).  Idle lanes (lane >= nl) carry lane 0's
+    // pixels: nothing reads their masses (the last active lane takes its right neighbour from the edge value) and
+    // their bounds are masked out of the row test below.
+    const bool act = lane < map.nl;
+    const int lastLane = map.nl - 1;
+    uint32_t mLs[NSEG], mRs[NSEG];
+#pragma unroll
+    for (int s = 0; s < NSEG; s++) {
+        const int dF = Map::segD0(s), dL = Map::segD0(s) + Map::segK(s) - 1;
+        uint32_t l = __builtin_amdgcn_update_dpp(0u, m[dL], DPP_WAVE_SHR1, 0xf, 0xf, false);
+        uint32_t r = __builtin_amdgcn_update_dpp(0u, m[dF], DPP_WAVE_SHL1, 0xf, 0xf, false);
+        uint32_t edgeL = m[dF], edgeR = m[dL];
+        if (s > 0)
+            edgeL = __builtin_amdgcn_readlane(m[Map::segD0(s - 1) + Map::segK(s - 1) - 1], lastLane);
+        if (s + 1 < NSEG)
+            edgeR = __builtin_amdgcn_readlane(m[Map::segD0(s + 1)], 0);
+        mLs[s] = lane == 0 ? edgeL : l;
+        mRs[s] = lane == lastLane ? edgeR : r;
+    }
+    constexpr int NG = K2BoundJob<NDW>::NG;
+    constexpr int GS = K2BoundJob<NDW>::GS;
+    static_assert(GS == 2 || NDW == 1, "the segment tables assume pairs of groups");
+    uint32_t B[NG];
+    uint32_t worst = 0; // OR of the bounds: each half >= that half of every group's bound (cheaper than a packed max)
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        const int g0 = GS * g, g1 = GS * g + GS - 1 < NDW ? GS * g + GS - 1 : NDW - 1; // first and last 4-pixel group
+        const int sg = Map::segOf(g0);
+        uint32_t own = m[g0];
+#pragma unroll
+        for (int q = g0 + 1; q <= g1; q++)
+            own += m[q];
+        const bool segStart = g0 == Map::segD0(sg), segEnd = g1 == Map::segD0(sg) + Map::segK(sg) - 1;
+        const uint32_t M = (segStart ? mLs[sg] : m[g0 - 1]) + own + (segEnd ? mRs[sg] : m[g1 + 1]);
+        if (K2BoundJob<NDW>::CASCADE) {
+            const uint32_t s1 = M + J.P[0][par ^ 1][g];
+            const uint32_t s2 = s1 + J.P[1][par ^ 1][g];
+            const uint32_t s3 = s2 + J.P[2][par ^ 1][g];
+            B[g] = s3 + J.P[3][par ^ 1][g];
+            J.P[0][par][g] = M;
+            J.P[1][par][g] = s1;
+            J.P[2][par][g] = s2;
+            J.P[3][par][g] = s3;
+        } else { // four in-place accumulators (b0, b1, b2, previous M): half the registers, a shift and a multiply more
+            B[g] = J.P[0][0][g] + M;
+            const uint32_t M4 = M << 2;
+            J.P[0][0][g] = J.P[1][0][g] + M4;
+            J.P[1][0][g] = pk_madk<6>(M, J.P[2][0][g]);
+            J.P[2][0][g] = J.P[3][0][g] + M4;
+            J.P[3][0][g] = M;
+        }
+        worst |= B[g];
+    }
+    const bool unsure = act && ((worst & 0xffffu) + (worst >> 16)) > 21u; // 6 * (lo + hi) < 128 <=> lo + hi <= 21
+    if (!(emit && __builtin_amdgcn_ballot_w64(unsure)))
+        return;
+    // ---- rare: some group of this row cannot be proven zero -----------------------------------------------
+    unsigned long long bm[NG]; // lanes whose recurrence group g (GS 4-pixel groups) is suspect
+    bool mine[NG];
+    uint32_t total = 0;
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        mine[g] = act && ((B[g] & 0xffffu) + (B[g] >> 16)) > 21u;
+        bm[g] = __builtin_amdgcn_ballot_w64(mine[g]);
+        const int nq = GS * g + GS <= NDW ? GS : NDW - GS * g; // 4-pixel groups of this recurrence group
+        total += (uint32_t)nq * (uint32_t)__builtin_popcountll(bm[g]);
+    }
+    J.hot += total > 32u; // one row of the row machine costs about as much as 30 exact groups
+    // (A full LDS list means a chunk with a lot of structure: for K2 the row machine is the cheaper way through such
+    // rows -- an exact group costs 45 window loads and two 5x5 sums --, so the list is NOT flushed to the global suspect
+    // list to make room, as K3 does; measured: flushing made the tail kernel 2.4x longer than the pieces it saved.)
+    if (J.hot >= 4u || J.npend + total > budget) {
+        J.handover = y; // dense rows (or the LDS list is full): the rest of the chunk goes to the row machine
+        return;
+    }
+    uint32_t base = J.npend;
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        const unsigned long long b = bm[g];
+        if (b) {
+            const int nq = GS * g + GS <= NDW ? GS : NDW - GS * g;
+            const int sg = Map::segOf(GS * g);
+            // global index of the recurrence group's first 4-pixel group
+            const uint32_t code0 = (uint32_t)y * ngroups + (uint32_t)(map.gbase[sg] + Map::segK(sg) * lane + (GS * g - Map::segD0(sg)));
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+            if (mine[g]) {
+#pragma unroll
+                for (int q = 0; q < nq; q++)
+                    pend[base + (uint32_t)nq * below + q] = code0 + q;
+            }
+            base += (uint32_t)nq * (uint32_t)__builtin_popcountll(b);
+        }
+    }
+    J.npend = base;
+}
+
+// Store mode of the bound-and-verify pass: a row the scan is responsible for (everything above the hand-over row) is
+// written as zeros by the scan itself -- proven rows ARE zero, and the few suspect groups of a row are overwritten by
+// the wave's own tail.
+template <int NDW>
+__device__ __forceinline__ void k2b_store_zero_row(uint8_t *__restrict__ row)
+{
+    uint32_t *po = reinterpret_cast<uint32_t *>(row);
+#pragma unroll
+    for (int d = 0; d < NDW; d++)
+        po[d] = 0;
+}
+
+// The wave's own tail (no global list, or it is full): D for the four pixels of every remembered group, one lane per
+// group; histogram by global atomics (rare), optional store / candidates.
+template <bool COMPACT, bool STORE>
+__device__ __forceinline__ void k2b_tail(const uint32_t *pend, uint32_t npend, const abub_job jb, const uint8_t *__restrict__ frames,
+                                         const uint8_t *__restrict__ sigma6, int W, int H, uint32_t *__restrict__ hist,
+                                         uint8_t *__restrict__ diff, const Compact &cp, int lane)
+{
+    if (npend == 0)
+        return;
+    wave_lds_fence(); // orders the scan's LDS writes before the reads below
+    const size_t P = (size_t)W * H;
+    const uint32_t ngroups = (uint32_t)W / 4;
+    const uint8_t *cur = frames + (size_t)jb.cur * P;
+    const uint8_t *ref = frames + (size_t)jb.ref * P;
+    const uint8_t *sg = sigma6 + (size_t)jb.model * P;
+    // with the fused candidate list the whole wave iterates together (the reservation shuffles)
+    const uint32_t nloop = COMPACT ? (npend + 63u) & ~63u : npend;
+#pragma unroll 1
+    for (uint32_t e = lane; e < nloop; e += 64) {
+        uint32_t packed = 0, pix0 = 0;
+        if (e < npend) {
+            const uint32_t code = pend[e];
+            const int y = (int)(code / ngroups), x0 = (int)(code % ngroups) * 4;
+            packed = k2_exact_group(cur, ref, sg, y, x0, W, H);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t d = (packed >> (8 * k)) & 0xffu;
+                if (d)
+                    atomicAdd(&hist[(size_t)jb.out * 256 + d], 1u);
+            }
+            if (STORE) // (the scan wrote this row as zeros; x0 is a multiple of 4 and W % 4 == 0: an aligned dword)
+                *reinterpret_cast<uint32_t *>(diff + (size_t)jb.out * P + (size_t)y * W + x0) = packed;
+            pix0 = (uint32_t)(y * W + x0);
+        }
+        if (COMPACT) { // candidates (value > cut) of the wave's groups: one reservation per wave
+            uint32_t c = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                c += (int)((packed >> (8 * k)) & 0xffu) > cp.thr;
+            uint32_t pos = compact_reserve(cp, c);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                compact_put(cp, pos, (packed >> (8 * k)) & 0xffu, pix0 + k);
+        }
+    }
+}
+
+template <int NDW, bool STORE, bool COMPACT>
+__global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ frames,
+                                                    const uint8_t *__restrict__ sigma6,
+                                                    const abub_job *__restrict__ jobs, int W, int H,
+                                                    int rows_per_chunk, int nchunks, uint32_t budget,
+                                                    uint2 *__restrict__ units, uint32_t *__restrict__ nunits,
+                                                    uint32_t *__restrict__ hist, uint8_t *__restrict__ diff,
+                                                    const int32_t *__restrict__ cthr, uint32_t *pairs, uint32_t pcap,
+                                                    uint32_t *pcount, uint32_t slot_base, SusList gl)
+{
+    constexpr int NP = 2 * NDW;
+    __shared__ uint32_t pend[K2B_PEND];
+    const int lane = threadIdx.x;
+    const int unit = blockIdx.x;
+    const int job = unit / nchunks;
+    const int chunk = unit - job * nchunks;
+    const abub_job jb = jobs[job];
+    const size_t P = (size_t)W * H;
+    const uint8_t *cur = frames + (size_t)jb.cur * P;
+    const uint8_t *ref = frames + (size_t)jb.ref * P;
+    const uint8_t *sg = sigma6 + (size_t)jb.model * P;
+    const int nl = W / (4 * NDW);
+    const bool active = lane < nl;
+    const int xoff = active ? lane * 4 * NDW : 0;
+    const int y0 = chunk * rows_per_chunk;
+    int y1 = y0 + rows_per_chunk;
+    if (y1 > H)
+        y1 = H;
+    const int T = y1 - y0 + 4; // input rows y0-2 .. y1+1 (reflected); step tt bounds output row y0+tt-4
+    const uint32_t ngroups = (uint32_t)W / 4;
+
+    ScanMap<NDW, false> map;
+    map.init(W);
+    K2BoundJob<NDW> J;
+#pragma unroll
+    for (int g = 0; g < K2BoundJob<NDW>::NG; g++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            J.P[q][0][g] = J.P[q][1][g] = 0;
+    J.npend = J.hot = 0;
+    J.jidx = (uint32_t)job;
+    J.handover = -1;
+    uint8_t *dbase = STORE ? diff + (size_t)jb.out * P + xoff : nullptr;
+
+    RowIn<NDW> ring[2];
+    k2_load_row<NDW>(ring[0], cur, ref, sg, reflect101(y0 - 2, H), W, xoff);
+    const int Tpad = (T + 1) & ~1;
+    for (int t = 0; t < Tpad && J.handover < 0; t += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int tt = t + u;
+            int tn = tt + 1 < T ? tt + 1 : T - 1;
+            k2_load_row<NDW>(ring[u ^ 1], cur, ref, sg, reflect101(y0 - 2 + tn, H), W, xoff);
+            if (J.handover < 0) {
+                uint32_t Xp[NP], Xn[NP];
+                k2_planes<NDW>(ring[u], Xp, Xn);
+                uint32_t m[NDW];
+#pragma unroll
+                for (int g = 0; g < NDW; g++)
+                    m[g] = (Xp[2 * g] + Xn[2 * g]) + (Xp[2 * g + 1] + Xn[2 * g + 1]);
+                k2b_row<NDW, false>(J, u, m, tt >= 4 && tt < T, y0 + tt - 4, map, lane, ngroups, budget, pend, gl);
+                if (STORE && tt >= 4 && tt < T && J.handover < 0 && active)
+                    k2b_store_zero_row<NDW>(dbase + (ptrdiff_t)(y0 + tt - 4) * W);
+            }
+        }
+    }
+    if (J.handover >= 0)
+        k2b_hand_over(units, nunits, (uint32_t)unit, J.handover, y1, lane);
+    if (J.npend) { // the suspects go to the launch's global list; if that is full the wave evaluates them itself
+        wave_lds_fence();
+        uint32_t gb = 0;
+        if (sus_reserve(J.npend, gl.list, gl.count, gl.cap, gb, lane)) {
+            sus_copy_out(pend, J.npend, J.jidx, gl.list, gb, lane);
+            return;
+        }
+    }
+    Compact cp;
+    cp.pairs = COMPACT ? pairs : nullptr;
+    cp.count = pcount;
+    cp.cap = pcap;
+    cp.slot = jb.out + slot_base;
+    cp.thr = COMPACT ? cthr[jb.out] : 255;
+    k2b_tail<COMPACT, STORE>(pend, J.npend, jb, frames, sigma6, W, H, hist, diff, cp, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k2_bound_chain: the bound scan for job lists with the trigger search's structure -- blocks of `L` consecutive jobs
+// in which job q takes the cur frame of job q - S as its ref (FindTriggerFrame: S = 2, or 1 for small training sets).
+// One wave serves up to K jobs of one such chain for one chunk: every frame row is loaded once and used as the cur
+// row of one job and the ref row of the next, sigma6 once for all -- (K + 2) / K row loads per job instead of 3.
+// The chain property is only a hint: the wave checks it on the job records and hands units it cannot chain to the row
+// machine, so any job list gives the same histograms as k2_bound_scan / k2_rows.
+// ------------------------------------------------------------------------------------------------
+template <int NDW, int K, bool STORE, bool SPLIT>
+__global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__ frames,
+                                                     const uint8_t *__restrict__ sigma6,
+                                                     const abub_job *__restrict__ jobs, int L, int S, int nslot, int W,
+                                                     int H, int rows_per_chunk, int nchunks, uint32_t budget,
+                                                     uint2 *__restrict__ units, uint32_t *__restrict__ nunits,
+                                                     uint32_t *__restrict__ hist, uint8_t *__restrict__ diff, SusList gl)
+{
+    __shared__ uint32_t pend[K][K2B_PEND];
+    const int lane = threadIdx.x;
+    const int chunk = blockIdx.x % nchunks;
+    const int bs = blockIdx.x / nchunks; // (block of L jobs, slot)
+    const int blk = bs / nslot;
+    int slot = bs - blk * nslot;
+    // slot -> (residue r, segment q of that residue's chain)
+    int r = 0, nr = 0;
+    for (r = 0; r < S; r++) {
+        nr = (L - r + S - 1) / S; // jobs of residue r in the block
+        const int ns = (nr + K - 1) / K;
+        if (slot < ns)
+            break;
+        slot -= ns;
+    }
+    const int k = nr - slot * K < K ? nr - slot * K : K; // jobs of this wave (>= 1)
+    K2BoundJob<NDW> J[K];
+    abub_job jb[K];
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+        const int tc = t < k ? t : k - 1;
+        J[t].jidx = (uint32_t)(blk * L + r + S * (slot * K + tc));
+        jb[t] = jobs[J[t].jidx];
+    }
+    const int y0 = chunk * rows_per_chunk;
+    int y1 = y0 + rows_per_chunk;
+    if (y1 > H)
+        y1 = H;
+    bool chained = true;
+#pragma unroll
+    for (int t = 1; t < K; t++)
+        if (t < k && (jb[t].ref != jb[t - 1].cur || jb[t].model != jb[0].model))
+            chained = false;
+    if (!chained) { // not the structure promised: every unit goes to the row machine whole
+#pragma unroll
+        for (int t = 0; t < K; t++)
+            if (t < k)
+                k2b_hand_over(units, nunits, J[t].jidx * (uint32_t)nchunks + (uint32_t)chunk, y0, y1, lane);
+        return;
+    }
+    const size_t P = (size_t)W * H;
+    const uint8_t *fp[K + 1];
+    fp[0] = frames + (size_t)jb[0].ref * P;
+#pragma unroll
+    for (int t = 0; t < K; t++)
+        fp[t + 1] = frames + (size_t)jb[t].cur * P;
+    const uint8_t *sg = sigma6 + (size_t)jb[0].model * P;
+    ScanMap<NDW, SPLIT> map;
+    map.init(W);
+    uint8_t *dbase[K];
+#pragma unroll
+    for (int t = 0; t < K; t++)
+        dbase[t] = STORE ? diff + (size_t)jb[t].out * P : nullptr;
+    const int T = y1 - y0 + 4;
+    const uint32_t ngroups = (uint32_t)W / 4;
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+#pragma unroll
+        for (int g = 0; g < K2BoundJob<NDW>::NG; g++)
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                J[t].P[q][0][g] = J[t].P[q][1][g] = 0;
+        J[t].npend = J[t].hot = 0;
+        J[t].handover = t < k ? -1 : 0x7fffffff; // (jobs beyond k do nothing and report nothing)
+    }
+
+    // rows are fetched one step ahead through two register sets ([K + 1] = sigma6); the loop is unrolled by two so
+    // that each set -- and each parity of the recurrence state -- is a fixed set of registers.  (Fetching two steps
+    // ahead was measured equal: the scan is bound by VALU issue at the clock the chip holds under HBM load.)
+    constexpr int PF = 1, U = 2;
+    uint32_t raw[U][K + 2][NDW];
+#define K2C_LOAD(SL, Y)                                                                       \
+    {                                                                                         \
+        const size_t o_ = (size_t)(Y) * W;                                                    \
+        _Pragma("unroll") for (int f = 0; f <= K; f++) map.load(raw[SL][f], fp[f] + o_, lane); \
+        map.load(raw[SL][K + 1], sg + o_, lane);                                              \
+    }
+#pragma unroll
+    for (int q = 0; q < PF; q++) {
+        const int tq = q < T ? q : T - 1;
+        K2C_LOAD(q, reflect101(y0 - 2 + tq, H));
+    }
+    const int Tpad = (T + U - 1) / U * U;
+    for (int t0 = 0; t0 < Tpad; t0 += U) {
+        bool all_done = true;
+#pragma unroll
+        for (int t = 0; t < K; t++)
+            all_done = all_done && J[t].handover >= 0;
+        if (all_done)
+            break;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int tt = t0 + u;
+            const int tn = tt + PF < T ? tt + PF : T - 1;
+            K2C_LOAD((u + PF) % U, reflect101(y0 - 2 + tn, H));
+            // widened frame rows (pw / cw) and frame + sigma6 (ps / cs): each is computed once per frame and serves the
+            // job that has the frame as cur and the job that has it as ref
+            uint32_t sw[2 * NDW], pw[2 * NDW], ps[2 * NDW];
+#pragma unroll
+            for (int d = 0; d < NDW; d++) {
+                sw[2 * d] = widen_lo(raw[u][K + 1][d]);
+                sw[2 * d + 1] = widen_hi(raw[u][K + 1][d]);
+                pw[2 * d] = widen_lo(raw[u][0][d]);
+                pw[2 * d + 1] = widen_hi(raw[u][0][d]);
+                ps[2 * d] = pw[2 * d] + sw[2 * d];
+                ps[2 * d + 1] = pw[2 * d + 1] + sw[2 * d + 1];
+            }
+#pragma unroll
+            for (int t = 0; t < K; t++) {
+                uint32_t cw[2 * NDW], cs[2 * NDW];
+#pragma unroll
+                for (int d = 0; d < NDW; d++) {
+                    cw[2 * d] = widen_lo(raw[u][t + 1][d]);
+                    cw[2 * d + 1] = widen_hi(raw[u][t + 1][d]);
+                    cs[2 * d] = cw[2 * d] + sw[2 * d];
+                    cs[2 * d + 1] = cw[2 * d + 1] + sw[2 * d + 1];
+                }
+                if (J[t].handover < 0) {
+                    uint32_t m[NDW];
+#pragma unroll
+                    for (int g = 0; g < NDW; g++) // sat(c - (r + s)) + sat(r - (c + s)), both pairs of the group
+                        m[g] = (pk_subsat(cw[2 * g], ps[2 * g]) + pk_subsat(pw[2 * g], cs[2 * g])) +
+                               (pk_subsat(cw[2 * g + 1], ps[2 * g + 1]) + pk_subsat(pw[2 * g + 1], cs[2 * g + 1]));
+                    k2b_row<NDW, SPLIT>(J[t], u, m, tt >= 4 && tt < T, y0 + tt - 4, map, lane, ngroups, budget, pend[t], gl);
+                    if (STORE && tt >= 4 && tt < T && J[t].handover < 0)
+                        map.store_zero(dbase[t] + (ptrdiff_t)(y0 + tt - 4) * W, lane);
+                }
+#pragma unroll
+                for (int j = 0; j < 2 * NDW; j++) {
+                    pw[j] = cw[j];
+                    ps[j] = cs[j];
+                }
+            }
+        }
+    }
+#undef K2C_LOAD
+    uint32_t tot = 0;
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+        if (t < k) {
+            if (J[t].handover >= 0)
+                k2b_hand_over(units, nunits, J[t].jidx * (uint32_t)nchunks + (uint32_t)chunk, J[t].handover, y1, lane);
+            tot += J[t].npend;
+        }
+    }
+    if (tot == 0)
+        return;
+    wave_lds_fence();
+    uint32_t gb = 0;
+    if (sus_reserve(tot, gl.list, gl.count, gl.cap, gb, lane)) { // the whole wave's suspects in one reservation
+#pragma unroll
+        for (int t = 0; t < K; t++)
+            if (t < k) {
+                sus_copy_out(pend[t], J[t].npend, J[t].jidx, gl.list, gb, lane);
+                gb += J[t].npend;
+            }
+        return;
+    }
+    Compact cp; // no room in the global list: the wave evaluates its suspects itself
+    cp.pairs = nullptr;
+    cp.count = nullptr;
+    cp.cap = 0;
+    cp.slot = 0;
+    cp.thr = 255;
+#pragma unroll
+    for (int t = 0; t < K; t++)
+        if (t < k)
+            k2b_tail<false, STORE>(pend[t], J[t].npend, jb[t], frames, sigma6, W, H, hist, diff, cp, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 generic: any W,H and the ROI overload.  256-thread workgroup, 32x8 output tile, LDS tile of
+// packed (pos | neg<<16) with a 2-pixel halo; borders reflect inside the ROI.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k2_generic(const uint8_t *__restrict__ frames,
+                                                  const uint8_t *__restrict__ sigma6,
+                                                  const abub_job *__restrict__ jobs,
+                                                  abub_job single, int use_single, int W, int H,
+                                                  int rx, int ry, int rw, int rh,
+                                                  uint32_t *__restrict__ hist,
+                                                  uint8_t *__restrict__ diff)
+{
+    __shared__ uint32_t tile[(G_TH + 4) * (G_TW + 4)];
+    __shared__ uint32_t lh[256];
+    const abub_job jb = use_single ? single : jobs[blockIdx.z];
+    const size_t P = (size_t)W * H;
+    const uint8_t *cur = frames + (size_t)jb.cur * P;
+    const uint8_t *ref = frames + (size_t)jb.ref * P;
+    const uint8_t *sg = sigma6 + (size_t)jb.model * P;
+    const int tid = threadIdx.x;
+    lh[tid] = 0;
+    const int tx0 = blockIdx.x * G_TW, ty0 = blockIdx.y * G_TH; // in ROI coordinates
+    for (int i = tid; i < (G_TH + 4) * (G_TW + 4); i += 256) {
+        int ly = i / (G_TW + 4), lx = i - ly * (G_TW + 4);
+        int x = reflect101(tx0 + lx - 2, rw) + rx;
+        int y = reflect101(ty0 + ly - 2, rh) + ry;
+        size_t o = (size_t)y * W + x;
+        int c = cur[o], r = ref[o], s6 = sg[o];
+        int pos = c - r;
+        pos = pos < 0 ? 0 : pos;
+        pos -= s6;
+        pos = pos < 0 ? 0 : pos;
+        int neg = r - c;
+        neg = neg < 0 ? 0 : neg;
+        neg -= s6;
+        neg = neg < 0 ? 0 : neg;
+        tile[i] = (uint32_t)pos | ((uint32_t)neg << 16);
+    }
+    __syncthreads();
+    const int lx = tid % G_TW, ly = tid / G_TW;
+    const int x = tx0 + lx, y = ty0 + ly;
+    if (x < rw && y < rh) {
+        const uint32_t w[5] = {1, 4, 6, 4, 1};
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            uint32_t rowacc = 0;
+#pragma unroll
+            for (int j = 0; j < 5; j++)
+                rowacc += w[j] * tile[(ly + i) * (G_TW + 4) + lx + j];
+            acc += w[i] * rowacc;
+        }
+        acc += 0x00800080u;
+        int a = (acc >> 8) & 0xff, b = acc >> 24;
+        int d = a > b ? a - b : b - a;
+        if (diff)
+            diff[(size_t)jb.out * P + (size_t)(y + ry) * W + (x + rx)] = (uint8_t)d;
+        if (d)
+            atomicAdd(&lh[d], 1u);
+    }
+    __syncthreads();
+    uint32_t v = lh[tid];
+    if (v && tid)
+        atomicAdd(&hist[(size_t)jb.out * 256 + tid], v);
+}
+
+template <int NDW, int PF>
+static void launch_k2_rows_pf(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
+                              int njobs, int W, int H, int R, int nchunks, uint32_t *hist, uint8_t *diff,
+                              const CompactArgs &ca, hipStream_t st)
+{
+    dim3 grid((unsigned)njobs * nchunks), block(64);
+#define K2_LAUNCH(ST, CO)                                                                                        \
+    hipLaunchKernelGGL((k2_rows<NDW, ST, PF, CO>), grid, block, 0, st, frames, sigma6, jobs, W, H, R, nchunks, \
+                       hist, diff, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base, nullptr, nullptr)
+    if (ca.cthr) {
+        if (diff)
+            K2_LAUNCH(true, true);
+        else
+            K2_LAUNCH(false, true);
+    } else {
+        if (diff)
+            K2_LAUNCH(true, false);
+        else
+            K2_LAUNCH(false, false);
+    }
+#undef K2_LAUNCH
+}
+
+// Tuning knobs of the K2 launchers.  Defaults come from the environment once (ABUB_K2_BOUND, ABUB_K2_CHAIN,
+// ABUB_K2_BUDGET, ABUB_K2_PF); abub_k2_set_option() overrides them at run time (tests and benches switch between
+// the bound-and-verify pass and the plain row machine inside one process).
+struct K2Options {
+    int bound = 1;     // 0: always the full row machine (k2_rows); 1: bound-and-verify (trigger-only AND store mode)
+    int chain = -1;    // jobs per wave in the chained scan: 2 or 3; 0 = never chain; -1 = automatic (3 for rows of up to
+                       // 5 dwords per lane -- measured 3 % faster at W = 1280 --, 2 for wider rows: registers)
+    int budget = 512;  // suspects a chunk may remember (LDS) before it hands its rows over (<= K2B_PEND)
+    int pf = 1;        // software-prefetch depth of the row machine in rows (1 or 2)
+    int split = 1;     // chained scan: "split" lane mapping where the row width allows it (0: always blocked)
+    int list = 0;      // 1: suspects go to a global list that a second kernel evaluates (sus_tail_list), 0: the scanning
+                       // waves evaluate their own.  K2's exact groups are expensive (45 window loads, two 5x5 sums) and few
+                       // per wave: measured on the bench's trigger pass, in-wave 2.36 ms vs 2.47 ms through the list (K3,
+                       // where every frame has its bubble and a group costs a 3x3 box, is the other way round: list always)
+    bool loaded = false;
+};
+static K2Options g_k2opt;
+static std::mutex g_k2optMu;
+static K2Options k2_options()
+{
+    std::lock_guard<std::mutex> lock(g_k2optMu);
+    if (!g_k2opt.loaded) {
+        if (const char *e = getenv("ABUB_K2_BOUND"))
+            g_k2opt.bound = atoi(e);
+        if (const char *e = getenv("ABUB_K2_CHAIN"))
+            g_k2opt.chain = atoi(e);
+        if (const char *e = getenv("ABUB_K2_BUDGET"))
+            if (atoi(e) > 0)
+                g_k2opt.budget = atoi(e);
+        if (const char *e = getenv("ABUB_K2_PF"))
+            g_k2opt.pf = atoi(e);
+        if (const char *e = getenv("ABUB_K2_SPLIT"))
+            g_k2opt.split = atoi(e);
+        if (const char *e = getenv("ABUB_K2_LIST"))
+            g_k2opt.list = atoi(e);
+        g_k2opt.loaded = true;
+    }
+    return g_k2opt;
+}
+
+extern "C" int abub_k2_set_option(const char *name, int value)
+{
+    if (!name)
+        return set_err(ABUB_E_INVALID, "abub_k2_set_option: null name");
+    (void)k2_options();
+    std::lock_guard<std::mutex> lock(g_k2optMu);
+    if (!strcmp(name, "bound"))
+        g_k2opt.bound = value;
+    else if (!strcmp(name, "chain"))
+        g_k2opt.chain = value;
+    else if (!strcmp(name, "budget") && value > 0)
+        g_k2opt.budget = value;
+    else if (!strcmp(name, "pf"))
+        g_k2opt.pf = value;
+    else if (!strcmp(name, "split"))
+        g_k2opt.split = value;
+    else if (!strcmp(name, "list"))
+        g_k2opt.list = value;
+    else
+        return set_err(ABUB_E_INVALID, "abub_k2_set_option: unknown option or bad value");
+    return ABUB_OK;
+}
+
+template <int NDW>
+static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
+                           int njobs, int W, int H, int R, int nchunks, uint32_t *hist, uint8_t *diff,
+                           const CompactArgs &ca, hipStream_t st)
+{
+    const K2Options opt = k2_options();
+    if (opt.bound && (size_t)H * (size_t)(W / 4) < ((size_t)1 << 32) && H < 65536) { // (row, group) codes are 32-bit
+        // bound-and-verify (see k2_bound_scan); with `diff` the scan also writes the rows it proves (or remembers)
+        const size_t nunits = (size_t)njobs * nchunks;
+        // a chunk remembers up to `budget` suspicious groups in LDS, then it hands its remaining rows to the row machine
+        const uint32_t budget = (uint32_t)(opt.budget < K2B_PEND ? opt.budget : K2B_PEND);
+        const size_t unitCap = nunits * (size_t)((R + K2B_SUB - 1) / K2B_SUB); // handed-over pieces, worst case
+        const size_t unitBytes = (unitCap * sizeof(uint2) + 255) & ~(size_t)255;
+        // the global suspect list (see sus_tail_list): room for 1024 groups per job on average within 64 K .. 16 M entries
+        size_t gcap = (size_t)njobs * 1024;
+        gcap = gcap < ((size_t)1 << 16) ? ((size_t)1 << 16) : (gcap > ((size_t)1 << 24) ? ((size_t)1 << 24) : gcap);
+        if (!opt.list)
+            gcap = 0;
+        const size_t bytes = 256 + unitBytes + gcap * sizeof(uint2) + 256;
+        std::unique_lock<std::mutex> hold;
+        uint8_t *scr = (uint8_t *)k2_scratch(st, bytes, hold);
+        if (!scr)
+            return set_err(ABUB_E_HIP, "abub_diff_hist_dev: scratch allocation failed");
+        uint32_t *counters = (uint32_t *)scr; // [0] = handed-over pieces, [32] = entries of the global suspect list
+        uint2 *units = (uint2 *)(scr + 256);
+        SusList gl;
+        gl.list = gcap ? (uint2 *)(scr + 256 + unitBytes) : nullptr;
+        gl.count = counters + 32;
+        gl.cap = (uint32_t)gcap;
+        const unsigned tgrid = (unsigned)((gcap + 256 * SUSL_UB - 1) / (256 * SUSL_UB) < 2048 ? (gcap + 256 * SUSL_UB - 1) / (256 * SUSL_UB) : 2048);
+        HIPCHK(hipMemsetAsync(counters, 0, 256, st));
+        const int L = ca.chain_len, S = ca.chain_stride;
+        const int chainK = opt.chain < 0 ? (NDW <= 5 ? 3 : 2) : opt.chain;
+        if (chainK >= 2 && L > 0 && S > 0 && S <= 8 && njobs % L == 0 && !ca.cthr) {
+            const int Kc = chainK >= 3 ? 3 : 2;
+            int nslot = 0;
+            for (int r = 0; r < S; r++) {
+                const int nr = (L - r + S - 1) / S;
+                nslot += nr > 0 ? (nr + Kc - 1) / Kc : 0;
+            }
+            const dim3 grid((unsigned)((size_t)(njobs / L) * nslot * nchunks));
+            // the scan's own lane mapping: whole 16 / 8 / 4-byte pieces per lane ("split") where the row decomposes
+            // that way (W = 1280, 1680, ...), the row machine's blocked mapping otherwise
+            // (measured, A/B on one box: store mode -13 % at W = 1280 and -4 % at 1680 -- the zero rows go out as whole
+            // lines --; trigger-only equal at 1280 and 2-7 % slower at 1680, where the three segments cost more
+            // neighbour-exchange instructions than the loads gain: split there only when D is stored)
+            constexpr bool CAN_SPLIT = NDW >= 5 && NDW <= 7;
+            const bool split = CAN_SPLIT && opt.split && (diff != nullptr || NDW == 5 || opt.split > 1);
+#define K2C_ARGS frames, sigma6, jobs, L, S, nslot, W, H, R, nchunks, budget, units, counters, hist, diff, gl
+#define K2C_LAUNCH_SP(KK, ST, SP) hipLaunchKernelGGL((k2_bound_chain<NDW, KK, ST, SP>), grid, dim3(64), 0, st, K2C_ARGS)
+#define K2C_LAUNCH(KK, ST)                                                                                          \
+    if (split) {                                                                                                    \
+        K2C_LAUNCH_SP(KK, ST, CAN_SPLIT);                                                                           \
+    } else {                                                                                                        \
+        K2C_LAUNCH_SP(KK, ST, false);                                                                               \
+    }
+            if (Kc == 3) {
+                if (diff) {
+                    K2C_LAUNCH(3, true);
+                } else {
+                    K2C_LAUNCH(3, false);
+                }
+            } else {
+                if (diff) {
+                    K2C_LAUNCH(2, true);
+                } else {
+                    K2C_LAUNCH(2, false);
+                }
+            }
+#undef K2C_LAUNCH_SP
+#undef K2C_ARGS
+#undef K2C_LAUNCH
+        } else {
+#define K2S_LAUNCH(ST, CO)                                                                                          \
+    hipLaunchKernelGGL((k2_bound_scan<NDW, ST, CO>), dim3((unsigned)nunits), dim3(64), 0, st, frames, sigma6, jobs, \
+                       W, H, R, nchunks, budget, units, counters, hist, diff, ca.cthr, ca.pairs, ca.cap, ca.count,  \
+                       ca.slot_base, gl)
+            if (ca.cthr) {
+                if (diff)
+                    K2S_LAUNCH(true, true);
+                else
+                    K2S_LAUNCH(false, true);
+            } else {
+                if (diff)
+                    K2S_LAUNCH(true, false);
+                else
+                    K2S_LAUNCH(false, false);
+            }
+#undef K2S_LAUNCH
+        }
+        // the suspects of all scanning waves, evaluated exactly (after the scan: in store mode it overwrites zero rows)
+        if (gl.list) {
+#define K2T_LAUNCH(CO, ST)                                                                                          \
+    hipLaunchKernelGGL((sus_tail_list<2, CO, ST>), dim3(tgrid), dim3(256), 0, st, frames, (const uint8_t *)nullptr,  \
+                       sigma6, jobs, W, H, hist, diff, gl.list, gl.count, gl.cap, ca.cthr, ca.pairs, ca.cap, ca.count, \
+                       ca.slot_base)
+            if (ca.cthr) {
+                if (diff) {
+                    K2T_LAUNCH(true, true);
+                } else {
+                    K2T_LAUNCH(true, false);
+                }
+            } else {
+                if (diff) {
+                    K2T_LAUNCH(false, true);
+                } else {
+                    K2T_LAUNCH(false, false);
+                }
+            }
+#undef K2T_LAUNCH
+        }
+        // the handed-over row ranges through the row machine's list mode (grid-stride over the pieces); with the fused
+        // candidate list (cthr) it emits the candidates, with `diff` it writes its rows
+        const unsigned g3 = (unsigned)(unitCap < 4096 ? unitCap : 4096);
+#define K2R_LAUNCH(ST, CO)                                                                                          \
+    hipLaunchKernelGGL((k2_rows<NDW, ST, 1, CO>), dim3(g3), dim3(64), 0, st, frames, sigma6, jobs, W, H, R, nchunks, \
+                       hist, diff, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base, units, counters)
+        if (ca.cthr) {
+            if (diff)
+                K2R_LAUNCH(true, true);
+            else
+                K2R_LAUNCH(false, true);
+        } else {
+            if (diff)
+                K2R_LAUNCH(true, false);
+            else
+                K2R_LAUNCH(false, false);
+        }
+#undef K2R_LAUNCH
+        return ABUB_OK;
+    }
+    // prefetch depth 1 won on MI355X: depth 2/3 rings cost a wave of occupancy and ran 10-17 % slower
+    // (measured in round 1, see DESIGN.md "Tuning log")
+    if (opt.pf == 2)
+        launch_k2_rows_pf<NDW, 2>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st);
+    else
+        launch_k2_rows_pf<NDW, 1>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st);
+    return ABUB_OK;
+}
+
+static int diff_hist_impl(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs, int njobs,
+                          int W, int H, uint32_t *hist, uint8_t *diff, int rows_per_chunk,
+                          const CompactArgs &ca, void *stream)
+{
+    if (!frames || !sigma6 || !jobs || !hist || W <= 0 || H <= 0 || njobs < 0 || rows_per_chunk < 0)
+        return set_err(ABUB_E_INVALID, "abub_diff_hist_dev: bad arguments");
+    if (njobs == 0)
+        return ABUB_OK;
+    hipStream_t st = (hipStream_t)stream;
+    // hist slots are jb.out-indexed; the caller guarantees out < nslots == njobs for stack batches.
+    // We zero and finalise exactly njobs consecutive slots starting at 0 (documented contract).
+    HIPCHK(hipMemsetAsync(hist, 0, (size_t)njobs * 256 * sizeof(uint32_t), st));
+    int ndw = pick_ndw(W);
+    if (ndw) {
+        int R = rows_per_chunk;
+        if (R == 0) {
+            // many jobs: 8 chunks per frame (<= ~3% vertical halo re-reads, chunk id == XCD id);
+            // fewer jobs: more, shorter chunks so that the launch still offers >= ~8k waves to the chip
+            int nch = 8;
+            if ((long long)njobs * nch < 8192)
+                nch = (8192 + njobs - 1) / njobs;
+            static int k2chunks = -1;
+            if (k2chunks < 0) {
+                const char *e = getenv("ABUB_K2_CHUNKS"); // tuning knob: chunks per frame (0 = automatic)
+                k2chunks = e ? atoi(e) : 0;
+            }
+            if (k2chunks > 0)
+                nch = k2chunks;
+            nch = (nch + 7) / 8 * 8; // keep chunk id == XCD id
+            R = (H + nch - 1) / nch;
+            if (R < 16)
+                R = 16;
+        }
+        int nchunks = (H + R - 1) / R;
+        int rc = ABUB_OK;
+        switch (ndw) {
+        case 1: rc = launch_k2_rows<1>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        case 2: rc = launch_k2_rows<2>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        case 3: rc = launch_k2_rows<3>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        case 4: rc = launch_k2_rows<4>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        case 5: rc = launch_k2_rows<5>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        case 6: rc = launch_k2_rows<6>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        case 7: rc = launch_k2_rows<7>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        default: rc = launch_k2_rows<8>(frames, sigma6, jobs, njobs, W, H, R, nchunks, hist, diff, ca, st); break;
+        }
+        if (rc != ABUB_OK)
+            return rc;
+    } else {
+        if (ca.cthr)
+            return set_err(ABUB_E_INVALID, "fused compaction needs the fast path (W % 4 == 0, W <= 2048)");
+        abub_job dummy = {0, 0, 0, 0};
+        dim3 grid((W + G_TW - 1) / G_TW, (H + G_TH - 1) / G_TH, njobs), block(256);
+        if (grid.z > 65535)
+            return set_err(ABUB_E_INVALID, "abub_diff_hist_dev: too many jobs for the generic kernel");
+        hipLaunchKernelGGL(k2_generic, grid, block, 0, st, frames, sigma6, jobs, dummy, 0, W, H, 0, 0,
+                           W, H, hist, diff);
+    }
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_hist_bin0, dim3(njobs), dim3(64), 0, st, hist, (uint32_t)((size_t)W * H));
+    HIPCHK(hipGetLastError());
+    return ABUB_OK;
+}
+
+extern "C" int abub_diff_hist_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
+                                  int njobs, int W, int H, uint32_t *hist, uint8_t *diff,
+                                  int rows_per_chunk, void *stream)
+{
+    CompactArgs ca = {nullptr, nullptr, 0, nullptr, 0};
+    return diff_hist_impl(frames, sigma6, jobs, njobs, W, H, hist, diff, rows_per_chunk, ca, stream);
+}
+
+extern "C" int abub_diff_hist_chained_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
+                                          int njobs, int W, int H, uint32_t *hist, int chain_len, int chain_stride,
+                                          void *stream)
+{
+    if (chain_len < 0 || chain_stride < 0)
+        return set_err(ABUB_E_INVALID, "abub_diff_hist_chained_dev: bad arguments");
+    CompactArgs ca = {nullptr, nullptr, 0, nullptr, 0};
+    ca.chain_len = chain_len;
+    ca.chain_stride = chain_stride;
+    return diff_hist_impl(frames, sigma6, jobs, njobs, W, H, hist, nullptr, 0, ca, stream);
+}
+
+extern "C" int abub_diff_hist_chained_store_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
+                                                int njobs, int W, int H, uint32_t *hist, uint8_t *diff, int chain_len,
+                                                int chain_stride, void *stream)
+{
+    if (chain_len < 0 || chain_stride < 0 || !diff)
+        return set_err(ABUB_E_INVALID, "abub_diff_hist_chained_store_dev: bad arguments");
+    CompactArgs ca = {nullptr, nullptr, 0, nullptr, 0};
+    ca.chain_len = chain_len;
+    ca.chain_stride = chain_stride;
+    return diff_hist_impl(frames, sigma6, jobs, njobs, W, H, hist, diff, 0, ca, stream);
+}
+
+extern "C" int abub_fast_path(int W) { return pick_ndw(W) != 0; }
+
+extern "C" int abub_diff_hist_compact_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs,
+                                          int njobs, int W, int H, uint32_t *hist, uint8_t *diff,
+                                          const int32_t *cthr, uint32_t *pairs, uint32_t cap,
+                                          uint32_t *count, uint32_t slot_base, void *stream)
+{
+    if (!cthr || !pairs || !count || cap == 0)
+        return set_err(ABUB_E_INVALID, "abub_diff_hist_compact_dev: bad arguments");
+    CompactArgs ca = {cthr, pairs, cap, count, slot_base};
+    return diff_hist_impl(frames, sigma6, jobs, njobs, W, H, hist, diff, 0, ca, stream);
+}
+
+extern "C" int abub_diff_roi_dev(const uint8_t *cur, const uint8_t *ref, const uint8_t *sigma6, int W,
+                                 int H, int rx, int ry, int rw, int rh, uint8_t *diff, uint32_t *hist,
+                                 void *stream)
+{
+    if (!cur || !ref || !sigma6 || !diff || !hist || W <= 0 || H <= 0 || rx < 0 || ry < 0 ||
+        rw < 0 || rh < 0 || rx + rw > W || ry + rh > H)
+        return set_err(ABUB_E_INVALID, "abub_diff_roi_dev: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    size_t P = (size_t)W * H;
+    HIPCHK(hipMemsetAsync(diff, 0, P, st)); // cv::Mat::zeros, AnalyzerUnit.cpp:349
+    HIPCHK(hipMemsetAsync(hist, 0, 256 * sizeof(uint32_t), st));
+    if (rw > 0 && rh > 0) {
+        // cur/ref/sigma6 are separate allocations: express them as frame offsets from `cur`... the
+        // generic kernel indexes frames by element count, so pass the three bases through pointer
+        // differences only when they share a slab.  Simplest exact way: one job with index 0 and
+        // dedicated base pointers.
+        abub_job jb = {0, 0, 0, 0};
+        dim3 grid((rw + G_TW - 1) / G_TW, (rh + G_TH - 1) / G_TH, 1), block(256);
+        // ref is addressed relative to cur: only valid if both lie in one slab at a multiple of P.
+        ptrdiff_t dref = ref - cur;
+        if (dref % (ptrdiff_t)P != 0 || dref < 0)
+            return set_err(ABUB_E_INVALID, "abub_diff_roi_dev: ref must follow cur in the same slab at a multiple of W*H");
+        jb.ref = (uint32_t)(dref / (ptrdiff_t)P);
+        hipLaunchKernelGGL(k2_generic, grid, block, 0, st, cur, sigma6, (const abub_job *)nullptr, jb, 1,
+                           W, H, rx, ry, rw, rh, hist, diff);
+        HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_hist_bin0, dim3(1), dim3(64), 0, st, hist, (uint32_t)P);
+    HIPCHK(hipGetLastError());
+    return ABUB_OK;
+}
