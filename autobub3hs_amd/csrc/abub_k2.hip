@@ -2,7 +2,7 @@
 // C-ABI launchers (include/abub_hip.h).  Kernel inventory: DESIGN.md section "Kernels".
 //   k2_rows<NDW,STORE,PF,COMPACT>  register-rolling row machine (optional stored image / fused candidate list; list mode
 //                                  for handed-over rows)
-//   k2_bound_chain / k2_bound_scan bound-and-verify: proves rows of D zero from a bound, lists the rest
+//   k2_sad_chain / k2_bound_scan   bound-and-verify: proves rows of D zero from a bound, lists the rest
 //   k2_generic                     same arithmetic, any size / ROI, LDS tile (also the ROI overload)
 #include "abub_dev.hpp"
 
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER
 //     S(y,x) <= sum_i w_i * 6 * M_g(y+i),   M_g(r) = m_{g-1}(r) + m_g(r) + m_{g+1}(r),   m_g = mass of X in group g
 // (every tap of the horizontal filter is <= 6 and reaches at most the neighbouring group; at the image edges the
 // reflected columns fall into the edge group itself, which the edge-replicated m_{-1} = m_0 counts a second time).
-//   k2_bound_scan / k2_bound_chain
+//   k2_bound_scan / k2_sad_chain
 //       one wave per (job, chunk) -- or per K chained jobs -- carries only this bound down the rows: the same
 //       1-4-6-4-1 recurrence, but on packed group masses instead of 4*NDW filtered pairs in two planes, and proves
 //       "D is zero" for whole rows with one ballot.  Groups it cannot prove are remembered in LDS (at most K2B_PEND
@@ -355,16 +355,48 @@ struct ScanMap {
         for (int s = 0; s < NSEG; s++)
             gbase[s] = nl * segD0(s);
     }
+    // the lane's piece of segment s as an UNSIGNED 32-bit byte offset: row pointer (wave-uniform, SGPRs) + zext(offset) lets
+    // the loads take the scalar-base + VGPR-offset form instead of a 64-bit VALU add per load
+    __device__ __forceinline__ uint32_t uoff(int s, int lane) const { return (uint32_t)byteoff(s, lane); }
     // byte offset of the lane's piece of segment s in a row (idle lanes shadow lane 0: valid address, results unused)
     __device__ __forceinline__ int byteoff(int s, int lane) const { return 4 * (gbase[s] + segK(s) * (lane < nl ? lane : 0)); }
     __device__ __forceinline__ void load(uint32_t (&r)[NDW], const uint8_t *__restrict__ row, int lane) const
     {
 #pragma unroll
         for (int s = 0; s < NSEG; s++) {
-            const uint32_t *p = reinterpret_cast<const uint32_t *>(row + byteoff(s, lane));
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(row + (size_t)uoff(s, lane));
 #pragma unroll
             for (int d = 0; d < segK(s); d++)
                 r[segD0(s) + d] = p[d];
+        }
+    }
+    // the same pieces through buffer addressing: `rs` describes the slab from a wave-uniform base, `soff` (SGPR) is the
+    // frame's and row's byte offset from it, the lane's piece offset is the only VGPR -- no VALU address arithmetic at all
+    template <int N>
+    static __device__ __forceinline__ void loadn(uint32_t *r, __amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
+    {
+        if constexpr (N >= 4) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+            r[0] = v[0], r[1] = v[1], r[2] = v[2], r[3] = v[3];
+            if constexpr (N > 4)
+                loadn<N - 4>(r + 4, rs, voff + 16u, soff);
+        } else if constexpr (N == 3) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)voff, (int)soff, 0);
+            r[0] = v[0], r[1] = v[1], r[2] = v[2];
+        } else if constexpr (N == 2) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, (int)soff, 0);
+            r[0] = v[0], r[1] = v[1];
+        } else {
+            r[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)soff, 0);
+        }
+    }
+    __device__ __forceinline__ void loadb(uint32_t (&r)[NDW], __amdgpu_buffer_rsrc_t rs, uint32_t soff, int lane) const
+    {
+        if constexpr (!SPLIT) {
+            loadn<NDW>(&r[0], rs, uoff(0, lane), soff);
+        } else {
+            loadn<4>(&r[0], rs, uoff(0, lane), soff);
+            loadn<NDW - 4>(&r[4], rs, uoff(NSEG - 1, lane), soff);
         }
     }
     __device__ __forceinline__ void store_zero(uint8_t *__restrict__ row, int lane) const
@@ -381,7 +413,7 @@ struct ScanMap {
     }
 };
 
-template <int NDW>
+template <int NDW, bool CASC = (NDW <= 5), bool PLAINM = false>
 struct K2BoundJob { // per-job state of the bound recurrence and of its suspect list (all wave-uniform but b*/Mprev)
     // The recurrence runs on PAIRS of 4-pixel groups (8 columns, the last one alone when NDW is odd): the taps of a
     // column still reach at most the neighbouring 4-pixel group on either side, so M = left group + own pair + right
@@ -392,8 +424,13 @@ struct K2BoundJob { // per-job state of the bound recurrence and of its suspect 
     // plain 32-bit adds and no shift / multiply; P[k][parity] = output of stage k at the previous row of that parity
     // (the row loops are unrolled by two, so nothing is ever copied).  Wide rows (NDW >= 6) keep the state in four
     // in-place accumulators instead (P[k][0]): 16 instead of 32 registers per job there, which is a wave of occupancy.
-    static constexpr bool CASCADE = NDW <= 5;
-    uint32_t P[4][2][NG];
+    static constexpr bool CASCADE = CASC;
+    // mass format: packed halves (mass of columns 0,2 | mass of columns 1,3) of the u16-pair arithmetic, a row is unsure
+    // when lo + hi > 21 -- or PLAIN = TWICE the group's mass as one u32 (the v_sad_u8 scan), unsure when > 42
+    static constexpr bool PLAIN = PLAINM;
+    static __device__ __forceinline__ bool over(uint32_t b) { return PLAINM ? b > 42u : ((b & 0xffffu) + (b >> 16)) > 21u; }
+    uint32_t P[4][CASC ? 2 : 1][NG];
+    uint32_t Mp[PLAINM ? 2 : 1][NG]; // PLAIN, in-place form: M of the previous row, by row parity (nothing is copied)
     uint32_t npend, hot, jidx;
     int handover; // < 0: scanning; >= 0: first output row left to the row machine (or "nothing to do")
 };
@@ -401,8 +438,8 @@ struct K2BoundJob { // per-job state of the bound recurrence and of its suspect 
 // one input row of one job: group masses m[] -> bound of output row y; suspects go to the job's LDS list.
 // Everything that steers control flow is read through SGPRs (ballots, s_bcnt1), so the scan loops compile to scalar
 // branches.
-template <int NDW, bool SPLIT>
-__device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const int par, uint32_t (&m)[NDW], bool emit, int y,
+template <int NDW, bool SPLIT, typename JOB>
+__device__ __forceinline__ void k2b_row(JOB &J, const int par, uint32_t (&m)[NDW], bool emit, int y,
                                         const ScanMap<NDW, SPLIT> &map, int lane, uint32_t ngroups, uint32_t budget,
                                         uint32_t *pend, const SusList &gl)
 {
@@ -429,8 +466,8 @@ __device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const int par, uint3
         mLs[s] = lane == 0 ? edgeL : l;
         mRs[s] = lane == lastLane ? edgeR : r;
     }
-    constexpr int NG = K2BoundJob<NDW>::NG;
-    constexpr int GS = K2BoundJob<NDW>::GS;
+    constexpr int NG = JOB::NG;
+    constexpr int GS = JOB::GS;
     static_assert(GS == 2 || NDW == 1, "the segment tables assume pairs of groups");
     uint32_t B[NG];
     uint32_t worst = 0; // OR of the bounds: each half >= that half of every group's bound (cheaper than a packed max)
@@ -444,7 +481,7 @@ __device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const int par, uint3
             own += m[q];
         const bool segStart = g0 == Map::segD0(sg), segEnd = g1 == Map::segD0(sg) + Map::segK(sg) - 1;
         const uint32_t M = (segStart ? mLs[sg] : m[g0 - 1]) + own + (segEnd ? mRs[sg] : m[g1 + 1]);
-        if (K2BoundJob<NDW>::CASCADE) {
+        if constexpr (JOB::CASCADE) {
             const uint32_t s1 = M + J.P[0][par ^ 1][g];
             const uint32_t s2 = s1 + J.P[1][par ^ 1][g];
             const uint32_t s3 = s2 + J.P[2][par ^ 1][g];
@@ -457,13 +494,18 @@ __device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const int par, uint3
             B[g] = J.P[0][0][g] + M;
             const uint32_t M4 = M << 2;
             J.P[0][0][g] = J.P[1][0][g] + M4;
-            J.P[1][0][g] = pk_madk<6>(M, J.P[2][0][g]);
-            J.P[2][0][g] = J.P[3][0][g] + M4;
-            J.P[3][0][g] = M;
+            J.P[1][0][g] = JOB::PLAIN ? __umul24(M, 6u) + J.P[2][0][g] : pk_madk<6>(M, J.P[2][0][g]); // (M < 2^24)
+            if constexpr (JOB::PLAIN) {
+                J.P[2][0][g] = J.Mp[par ^ 1][g] + M4;
+                J.Mp[par][g] = M;
+            } else {
+                J.P[2][0][g] = J.P[3][0][g] + M4;
+                J.P[3][0][g] = M;
+            }
         }
-        worst |= B[g];
+        worst = JOB::PLAIN ? (B[g] > worst ? B[g] : worst) : (worst | B[g]);
     }
-    const bool unsure = act && ((worst & 0xffffu) + (worst >> 16)) > 21u; // 6 * (lo + hi) < 128 <=> lo + hi <= 21
+    const bool unsure = act && JOB::over(worst); // 6 * mass < 128 <=> mass <= 21 (packed: lo + hi; plain: twice the mass <= 42)
     if (!(emit && __builtin_amdgcn_ballot_w64(unsure)))
         return;
     // ---- rare: some group of this row cannot be proven zero -----------------------------------------------
@@ -472,7 +514,7 @@ __device__ __forceinline__ void k2b_row(K2BoundJob<NDW> &J, const int par, uint3
     uint32_t total = 0;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
-        mine[g] = act && ((B[g] & 0xffffu) + (B[g] >> 16)) > 21u;
+        mine[g] = act && JOB::over(B[g]);
         bm[g] = __builtin_amdgcn_ballot_w64(mine[g]);
         const int nq = GS * g + GS <= NDW ? GS : NDW - GS * g; // 4-pixel groups of this recurrence group
         total += (uint32_t)nq * (uint32_t)__builtin_popcountll(bm[g]);
@@ -603,7 +645,7 @@ __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ 
     for (int g = 0; g < K2BoundJob<NDW>::NG; g++)
 #pragma unroll
         for (int q = 0; q < 4; q++)
-            J.P[q][0][g] = J.P[q][1][g] = 0;
+            J.P[q][0][g] = J.P[q][K2BoundJob<NDW>::CASCADE ? 1 : 0][g] = 0;
     J.npend = J.hot = 0;
     J.jidx = (uint32_t)job;
     J.handover = -1;
@@ -650,46 +692,103 @@ __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ 
     k2b_tail<COMPACT, STORE>(pend, J.npend, jb, frames, sigma6, W, H, hist, diff, cp, lane);
 }
 
+#define K2C_MAXW 8 /* waves per workgroup of the chained scan, at most */
+#ifndef K2C_DEFAULT_WG
+#define K2C_DEFAULT_WG 1
+#endif
+#ifndef K2C_DEFAULT_SYNC
+#define K2C_DEFAULT_SYNC 0
+#endif
 // ------------------------------------------------------------------------------------------------
-// k2_bound_chain: the bound scan for job lists with the trigger search's structure -- blocks of `L` consecutive jobs
-// in which job q takes the cur frame of job q - S as its ref (FindTriggerFrame: S = 2, or 1 for small training sets).
-// One wave serves up to K jobs of one such chain for one chunk: every frame row is loaded once and used as the cur
-// row of one job and the ref row of the next, sigma6 once for all -- (K + 2) / K row loads per job instead of 3.
+// k2_sad_chain: the bound scan for job lists with the trigger search's structure -- blocks of `L` consecutive jobs in
+// which job q takes the cur frame of job q - S as its ref (FindTriggerFrame: S = 2, or 1 for small training sets).
+// One wave serves up to K jobs of one such chain for one chunk: every frame row is loaded once and serves the job that
+// has it as cur and the job that has it as ref, sigma6 once for all -- (K + 2) / K row loads per job instead of 3.
 // The chain property is only a hint: the wave checks it on the job records and hands units it cannot chain to the row
 // machine, so any job list gives the same histograms as k2_bound_scan / k2_rows.
+//
+// Group masses come from v_sad_u8, not from u16-pair arithmetic:
+//   X = sat(c - r - s) + sat(r - c - s) is symmetric in its two frames, and with HI = min(r + s, 255), LO = sat(r - s)
+//   (packed bytes) the mass of a 4-pixel group is
+//       2 * sum_b X_b = SAD(c, HI) + SAD(c, LO) - SAD(HI, LO)          (c inside [LO, HI]: the first two add up to HI - LO)
+//   -- exact, two v_sad_u8 per dword and job once HI / LO / -SAD(HI, LO) of ONE of the job's frames are in registers.
+//   In a chain f0 f1 .. fK (job t = (cur f[t+1], ref f[t])) the odd frames f1, f3, .. are the ones that get HI / LO: job
+//   t - 1 meets f[t] as its cur, job t as its ref, so every HI / LO pair serves two jobs and the even frames are never
+//   widened at all.  Per dword and job: 7 quarter-rate VALU instructions (2 SAD + half of: 2 widen, 2 add-sat, 2 sub-sat,
+//   2 pack, 1 SAD, + sigma6's widening) where the u16-pair form of round 2 needed 7.3 + 5.7 full-rate ones (4.6 instead of
+//   5.7 VALU instructions per pixel in all); the bound, the suspect lists, hand-over and tails are k2b_row's, fed with
+//   twice the mass as a plain u32 (K2BoundJob<.., PLAIN>).  Four in-place accumulators per recurrence group (12 registers
+//   per job at NDW = 5) leave room for K = 4 jobs per wave.
+//
+// Workgroups of NW > 1 waves (option "wg", off by default): the waves are consecutive segments of ONE chain on the same
+// chunk, sharing nothing but progress words in LDS (option "sync": a wave more than `sync` row steps ahead of the slowest
+// one naps), so that the frame two neighbouring segments share is asked for by both within microseconds and the second
+// request hits the XCD's L2.  Measured: HBM traffic per job falls from 1.24 to 1.12 W*H, the pass
+// gets 2 - 20 % SLOWER -- the pass is bound by neither bytes nor VALU issue alone.
 // ------------------------------------------------------------------------------------------------
-template <int NDW, int K, bool STORE, bool SPLIT>
-__global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__ frames,
-                                                     const uint8_t *__restrict__ sigma6,
-                                                     const abub_job *__restrict__ jobs, int L, int S, int nslot, int W,
-                                                     int H, int rows_per_chunk, int nchunks, uint32_t budget,
-                                                     uint2 *__restrict__ units, uint32_t *__restrict__ nunits,
-                                                     uint32_t *__restrict__ hist, uint8_t *__restrict__ diff, SusList gl)
+__device__ __forceinline__ uint32_t pk_addsat(uint32_t a, uint32_t b)
 {
-    __shared__ uint32_t pend[K][K2B_PEND];
-    const int lane = threadIdx.x;
+    u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(x, y));
+}
+// bytes (b0,b1) / (b2,b3) of a dword into the HIGH bytes of two u16 lanes: a saturating u16 add / sub of two such
+// values leaves min(x + y, 255) / max(x - y, 0) in the high byte
+__device__ __forceinline__ uint32_t widen8_lo(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x010c000cu); }
+__device__ __forceinline__ uint32_t widen8_hi(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x030c020cu); }
+// the high bytes of the lanes of (a: pixels 0,1; b: pixels 2,3) packed back into one dword
+__device__ __forceinline__ uint32_t pack8(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07050301u); }
+
+template <int NDW, int K, bool STORE, bool SPLIT, int PF = 1>
+__global__ __launch_bounds__(64 * K2C_MAXW) void k2_sad_chain(const uint8_t *__restrict__ frames,
+                                                   const uint8_t *__restrict__ sigma6,
+                                                   const abub_job *__restrict__ jobs, int L, int S, int nwgs, int W,
+                                                   int H, int rows_per_chunk, int nchunks, uint32_t budget,
+                                                   uint2 *__restrict__ units, uint32_t *__restrict__ nunits,
+                                                   uint32_t *__restrict__ hist, uint8_t *__restrict__ diff, SusList gl,
+                                                   int syncD)
+{
+    using Job = K2BoundJob<NDW, false, true>;
+    // dynamic LDS: [NW][K][K2B_PEND] suspect lists (one set per wave), then [NW] progress words.  Progress word of a wave =
+    // the row step it is about to start; 0x7fffffff once it no longer loads rows.  No barrier anywhere: the slowest wave
+    // never waits, a finished wave counts as infinitely far ahead.
+    extern __shared__ uint32_t k2c_lds[];
+    const int NW = (int)(blockDim.x >> 6);
+    const int lane = (int)(threadIdx.x & 63u);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t(*pend)[K2B_PEND] = reinterpret_cast<uint32_t(*)[K2B_PEND]>(k2c_lds + (size_t)wave * K * K2B_PEND);
+    // (relaxed workgroup-scope LDS atomics, NOT volatile accesses: those go through a generic pointer and compile to FLAT
+    // instructions, and one pending FLAT operation turns every vmcnt wait of the row loop into vmcnt(0))
+    const int progBase = NW * K * K2B_PEND;
+#define K2C_PUBLISH(V)                                                                                         \
+    {                                                                                                          \
+        if (NW > 1 && lane == 0)                                                                               \
+            __hip_atomic_store(&k2c_lds[progBase + wave], (uint32_t)(V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    }
     const int chunk = blockIdx.x % nchunks;
-    const int bs = blockIdx.x / nchunks; // (block of L jobs, slot)
-    const int blk = bs / nslot;
-    int slot = bs - blk * nslot;
-    // slot -> (residue r, segment q of that residue's chain)
-    int r = 0, nr = 0;
+    const int bs = blockIdx.x / nchunks;
+    const int blk = bs / nwgs;
+    int wg = bs - blk * nwgs;
+    int r = 0, nr = 0, ns = 0;
     for (r = 0; r < S; r++) {
-        nr = (L - r + S - 1) / S; // jobs of residue r in the block
-        const int ns = (nr + K - 1) / K;
-        if (slot < ns)
+        nr = (L - r + S - 1) / S;
+        ns = (nr + K - 1) / K;
+        const int nw = (ns + NW - 1) / NW;
+        if (wg < nw)
             break;
-        slot -= ns;
+        wg -= nw;
+    }
+    const int slot = wg * NW + wave;
+    if (r >= S || slot >= ns) {
+        K2C_PUBLISH(0x7fffffff);
+        return;
     }
     const int k = nr - slot * K < K ? nr - slot * K : K; // jobs of this wave (>= 1)
-    K2BoundJob<NDW> J[K];
-    abub_job jb[K];
+    Job J[K];
+    abub_job jb[K]; // (only alive up to the frame offsets below: the tails read their job records again)
+    const uint32_t jidx0 = (uint32_t)(blk * L + r + S * slot * K); // job t of this wave = jidx0 + S * t
 #pragma unroll
-    for (int t = 0; t < K; t++) {
-        const int tc = t < k ? t : k - 1;
-        J[t].jidx = (uint32_t)(blk * L + r + S * (slot * K + tc));
-        jb[t] = jobs[J[t].jidx];
-    }
+    for (int t = 0; t < K; t++)
+        jb[t] = jobs[jidx0 + (uint32_t)(S * (t < k ? t : k - 1))];
     const int y0 = chunk * rows_per_chunk;
     int y1 = y0 + rows_per_chunk;
     if (y1 > H)
@@ -703,7 +802,8 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
 #pragma unroll
         for (int t = 0; t < K; t++)
             if (t < k)
-                k2b_hand_over(units, nunits, J[t].jidx * (uint32_t)nchunks + (uint32_t)chunk, y0, y1, lane);
+                k2b_hand_over(units, nunits, (jidx0 + (uint32_t)(S * t)) * (uint32_t)nchunks + (uint32_t)chunk, y0, y1, lane);
+        K2C_PUBLISH(0x7fffffff);
         return;
     }
     const size_t P = (size_t)W * H;
@@ -724,19 +824,22 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
 #pragma unroll
     for (int t = 0; t < K; t++) {
 #pragma unroll
-        for (int g = 0; g < K2BoundJob<NDW>::NG; g++)
+        for (int g = 0; g < Job::NG; g++)
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                J[t].P[q][0][g] = J[t].P[q][1][g] = 0;
+                J[t].P[q][0][g] = 0;
+#pragma unroll
+        for (int g = 0; g < Job::NG; g++)
+            J[t].Mp[0][g] = J[t].Mp[1][g] = 0;
         J[t].npend = J[t].hot = 0;
         J[t].handover = t < k ? -1 : 0x7fffffff; // (jobs beyond k do nothing and report nothing)
     }
-
-    // rows are fetched one step ahead through two register sets ([K + 1] = sigma6); the loop is unrolled by two so
-    // that each set -- and each parity of the recurrence state -- is a fixed set of registers.  (Fetching two steps
-    // ahead was measured equal: the scan is bound by VALU issue at the clock the chip holds under HBM load.)
-    constexpr int PF = 1, U = 2;
-    uint32_t raw[U][K + 2][NDW];
+    // rows are fetched PF steps ahead through a ring of PF + 1 register sets ([K + 1] = sigma6); the loop is unrolled by
+    // U = lcm(PF + 1, 2) so that ring slots and the parity of the recurrence state are compile-time registers.
+    // (Plain global loads: buffer addressing -- scalar base and row offset, no VALU address arithmetic -- was measured
+    // 1 - 3 % SLOWER on this pass.)
+    constexpr int RING = PF + 1, U = (RING % 2 == 0) ? RING : 2 * RING;
+    uint32_t raw[RING][K + 2][NDW];
 #define K2C_LOAD(SL, Y)                                                                       \
     {                                                                                         \
         const size_t o_ = (size_t)(Y) * W;                                                    \
@@ -756,58 +859,76 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
             all_done = all_done && J[t].handover >= 0;
         if (all_done)
             break;
+        if (NW > 1) { // publish the row step, nap while too far ahead of the workgroup's slowest wave
+            K2C_PUBLISH(t0);
+            if (syncD > 0) {
+                for (;;) {
+                    int mn = 0x7fffffff;
+                    for (int w = 0; w < NW; w++) {
+                        const int pw_ = (int)__hip_atomic_load(&k2c_lds[progBase + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        mn = pw_ < mn ? pw_ : mn;
+                    }
+                    if (t0 <= __builtin_amdgcn_readfirstlane(mn) + syncD)
+                        break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+        }
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int tt = t0 + u;
+        for (int uu = 0; uu < U; uu++) {
+            const int tt = t0 + uu;
             const int tn = tt + PF < T ? tt + PF : T - 1;
-            K2C_LOAD((u + PF) % U, reflect101(y0 - 2 + tn, H));
-            // widened frame rows (pw / cw) and frame + sigma6 (ps / cs): each is computed once per frame and serves the
-            // job that has the frame as cur and the job that has it as ref
-            uint32_t sw[2 * NDW], pw[2 * NDW], ps[2 * NDW];
+            K2C_LOAD((uu + PF) % RING, reflect101(y0 - 2 + tn, H));
+            const int u = uu % RING; // ring slot of this step's rows
+            const int par = uu & 1;  // parity of the recurrence state
+            const bool emit = tt >= 4 && tt < T;
+            const int y = y0 + tt - 4;
+            uint32_t s8[2 * NDW]; // sigma6 in the high bytes of u16 lanes
 #pragma unroll
             for (int d = 0; d < NDW; d++) {
-                sw[2 * d] = widen_lo(raw[u][K + 1][d]);
-                sw[2 * d + 1] = widen_hi(raw[u][K + 1][d]);
-                pw[2 * d] = widen_lo(raw[u][0][d]);
-                pw[2 * d + 1] = widen_hi(raw[u][0][d]);
-                ps[2 * d] = pw[2 * d] + sw[2 * d];
-                ps[2 * d + 1] = pw[2 * d + 1] + sw[2 * d + 1];
+                s8[2 * d] = widen8_lo(raw[u][K + 1][d]);
+                s8[2 * d + 1] = widen8_hi(raw[u][K + 1][d]);
             }
 #pragma unroll
-            for (int t = 0; t < K; t++) {
-                uint32_t cw[2 * NDW], cs[2 * NDW];
+            for (int h = 1; h <= K; h += 2) { // frame h gets HI / LO: it is the cur of job h - 1 and the ref of job h
+                const bool ja = J[h - 1].handover < 0, jc = h < K && J[h < K ? h : K - 1].handover < 0;
+                if (!(ja || jc))
+                    continue;
+                uint32_t HI[NDW], LO[NDW], nS[NDW];
 #pragma unroll
                 for (int d = 0; d < NDW; d++) {
-                    cw[2 * d] = widen_lo(raw[u][t + 1][d]);
-                    cw[2 * d + 1] = widen_hi(raw[u][t + 1][d]);
-                    cs[2 * d] = cw[2 * d] + sw[2 * d];
-                    cs[2 * d + 1] = cw[2 * d + 1] + sw[2 * d + 1];
-                }
-                if (J[t].handover < 0) {
-                    uint32_t m[NDW];
-#pragma unroll
-                    for (int g = 0; g < NDW; g++) // sat(c - (r + s)) + sat(r - (c + s)), both pairs of the group
-                        m[g] = (pk_subsat(cw[2 * g], ps[2 * g]) + pk_subsat(pw[2 * g], cs[2 * g])) +
-                               (pk_subsat(cw[2 * g + 1], ps[2 * g + 1]) + pk_subsat(pw[2 * g + 1], cs[2 * g + 1]));
-                    k2b_row<NDW, SPLIT>(J[t], u, m, tt >= 4 && tt < T, y0 + tt - 4, map, lane, ngroups, budget, pend[t], gl);
-                    if (STORE && tt >= 4 && tt < T && J[t].handover < 0)
-                        map.store_zero(dbase[t] + (ptrdiff_t)(y0 + tt - 4) * W, lane);
+                    const uint32_t r0 = widen8_lo(raw[u][h][d]), r1 = widen8_hi(raw[u][h][d]);
+                    HI[d] = pack8(pk_addsat(r0, s8[2 * d]), pk_addsat(r1, s8[2 * d + 1]));
+                    LO[d] = pack8(pk_subsat(r0, s8[2 * d]), pk_subsat(r1, s8[2 * d + 1]));
+                    nS[d] = 0u - __builtin_amdgcn_sad_u8(HI[d], LO[d], 0u);
                 }
 #pragma unroll
-                for (int j = 0; j < 2 * NDW; j++) {
-                    pw[j] = cw[j];
-                    ps[j] = cs[j];
+                for (int q = 0; q < 2; q++) { // q = 0: job h - 1 against frame h - 1; q = 1: job h against frame h + 1
+                    const int t = h - 1 + q, fc = q ? h + 1 : h - 1;
+                    if (t >= K)
+                        continue;
+                    if (J[t].handover < 0) {
+                        uint32_t m[NDW];
+#pragma unroll
+                        for (int d = 0; d < NDW; d++)
+                            m[d] = __builtin_amdgcn_sad_u8(raw[u][fc][d], LO[d], __builtin_amdgcn_sad_u8(raw[u][fc][d], HI[d], nS[d]));
+                        k2b_row<NDW, SPLIT>(J[t], par, m, emit, y, map, lane, ngroups, budget, pend[t], gl);
+                        if (STORE && emit && J[t].handover < 0)
+                            map.store_zero(dbase[t] + (ptrdiff_t)y * W, lane);
+                    }
                 }
             }
         }
     }
 #undef K2C_LOAD
+    K2C_PUBLISH(0x7fffffff); // the scan is over: nobody waits for this wave's tail
+#undef K2C_PUBLISH
     uint32_t tot = 0;
 #pragma unroll
     for (int t = 0; t < K; t++) {
         if (t < k) {
             if (J[t].handover >= 0)
-                k2b_hand_over(units, nunits, J[t].jidx * (uint32_t)nchunks + (uint32_t)chunk, J[t].handover, y1, lane);
+                k2b_hand_over(units, nunits, (jidx0 + (uint32_t)(S * t)) * (uint32_t)nchunks + (uint32_t)chunk, J[t].handover, y1, lane);
             tot += J[t].npend;
         }
     }
@@ -819,7 +940,7 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
 #pragma unroll
         for (int t = 0; t < K; t++)
             if (t < k) {
-                sus_copy_out(pend[t], J[t].npend, J[t].jidx, gl.list, gb, lane);
+                sus_copy_out(pend[t], J[t].npend, jidx0 + (uint32_t)(S * t), gl.list, gb, lane);
                 gb += J[t].npend;
             }
         return;
@@ -833,7 +954,7 @@ __global__ __launch_bounds__(64) void k2_bound_chain(const uint8_t *__restrict__
 #pragma unroll
     for (int t = 0; t < K; t++)
         if (t < k)
-            k2b_tail<false, STORE>(pend[t], J[t].npend, jb[t], frames, sigma6, W, H, hist, diff, cp, lane);
+            k2b_tail<false, STORE>(pend[t], J[t].npend, jobs[jidx0 + (uint32_t)(S * t)], frames, sigma6, W, H, hist, diff, cp, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -930,15 +1051,19 @@ static void launch_k2_rows_pf(const uint8_t *frames, const uint8_t *sigma6, cons
 // the bound-and-verify pass and the plain row machine inside one process).
 struct K2Options {
     int bound = 1;     // 0: always the full row machine (k2_rows); 1: bound-and-verify (trigger-only AND store mode)
-    int chain = -1;    // jobs per wave in the chained scan: 2 or 3; 0 = never chain; -1 = automatic (3 for rows of up to
-                       // 5 dwords per lane -- measured 3 % faster at W = 1280 --, 2 for wider rows: registers)
+    int chain = -1;    // jobs per wave in the chained scan: 2 or 4 (>= 3 means 4); 0 = never chain; -1 = automatic (4)
     int budget = 512;  // suspects a chunk may remember (LDS) before it hands its rows over (<= K2B_PEND)
     int pf = 1;        // software-prefetch depth of the row machine in rows (1 or 2)
+    int scanpf = -1;   // chained scan: rows fetched ahead, 1 or 2 (-1 = automatic: 2 where that is instantiated and measured faster)
     int split = 1;     // chained scan: "split" lane mapping where the row width allows it (0: always blocked)
     int list = 0;      // 1: suspects go to a global list that a second kernel evaluates (sus_tail_list), 0: the scanning
                        // waves evaluate their own.  K2's exact groups are expensive (45 window loads, two 5x5 sums) and few
                        // per wave: measured on the bench's trigger pass, in-wave 2.36 ms vs 2.47 ms through the list (K3,
                        // where every frame has its bubble and a group costs a 3x3 box, is the other way round: list always)
+    int wg = -1;       // chained scan: waves per workgroup (1 .. K2C_MAXW) = consecutive segments of one chain (k2_sad_chain);
+                       // -1 = automatic (K2C_DEFAULT_WG)
+    int sync = -1;     // chained scan: row steps a wave may run ahead of its workgroup's slowest wave (0 = never waits;
+                       // -1 = automatic, K2C_DEFAULT_SYNC)
     bool loaded = false;
 };
 static K2Options g_k2opt;
@@ -960,6 +1085,12 @@ static K2Options k2_options()
             g_k2opt.split = atoi(e);
         if (const char *e = getenv("ABUB_K2_LIST"))
             g_k2opt.list = atoi(e);
+        if (const char *e = getenv("ABUB_K2_WG"))
+            g_k2opt.wg = atoi(e);
+        if (const char *e = getenv("ABUB_K2_SYNC"))
+            g_k2opt.sync = atoi(e);
+        if (const char *e = getenv("ABUB_K2_SCANPF"))
+            g_k2opt.scanpf = atoi(e);
         g_k2opt.loaded = true;
     }
     return g_k2opt;
@@ -983,6 +1114,12 @@ extern "C" int abub_k2_set_option(const char *name, int value)
         g_k2opt.split = value;
     else if (!strcmp(name, "list"))
         g_k2opt.list = value;
+    else if (!strcmp(name, "wg"))
+        g_k2opt.wg = value;
+    else if (!strcmp(name, "sync"))
+        g_k2opt.sync = value;
+    else if (!strcmp(name, "scanpf"))
+        g_k2opt.scanpf = value;
     else
         return set_err(ABUB_E_INVALID, "abub_k2_set_option: unknown option or bad value");
     return ABUB_OK;
@@ -1020,42 +1157,52 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
         const unsigned tgrid = (unsigned)((gcap + 256 * SUSL_UB - 1) / (256 * SUSL_UB) < 2048 ? (gcap + 256 * SUSL_UB - 1) / (256 * SUSL_UB) : 2048);
         HIPCHK(hipMemsetAsync(counters, 0, 256, st));
         const int L = ca.chain_len, S = ca.chain_stride;
-        const int chainK = opt.chain < 0 ? (NDW <= 5 ? 3 : 2) : opt.chain;
+        // jobs per wave: 4 (automatic) or 2 (option "chain" = 2)
+        const int chainK = opt.chain < 0 ? 4 : opt.chain;
         if (chainK >= 2 && L > 0 && S > 0 && S <= 8 && njobs % L == 0 && !ca.cthr) {
-            const int Kc = chainK >= 3 ? 3 : 2;
-            int nslot = 0;
+            const int Kc = chainK >= 3 ? 4 : 2; // (the grid below must agree with the kernel's K)
+            const int NW = opt.wg < 0 ? K2C_DEFAULT_WG : (opt.wg < 1 ? 1 : (opt.wg > K2C_MAXW ? K2C_MAXW : opt.wg));
+            int nwgs = 0; // workgroups per block of L jobs: NW consecutive segments of Kc jobs each, per residue chain
             for (int r = 0; r < S; r++) {
                 const int nr = (L - r + S - 1) / S;
-                nslot += nr > 0 ? (nr + Kc - 1) / Kc : 0;
+                const int ns = nr > 0 ? (nr + Kc - 1) / Kc : 0;
+                nwgs += (ns + NW - 1) / NW;
             }
-            const dim3 grid((unsigned)((size_t)(njobs / L) * nslot * nchunks));
-            // the scan's own lane mapping: whole 16 / 8 / 4-byte pieces per lane ("split") where the row decomposes
-            // that way (W = 1280, 1680, ...), the row machine's blocked mapping otherwise
-            // (measured, A/B on one box: store mode -13 % at W = 1280 and -4 % at 1680 -- the zero rows go out as whole
-            // lines --; trigger-only equal at 1280 and 2-7 % slower at 1680, where the three segments cost more
-            // neighbour-exchange instructions than the loads gain: split there only when D is stored)
+            const dim3 grid((unsigned)((size_t)(njobs / L) * nwgs * nchunks));
+            const size_t ldsBytes = ((size_t)NW * Kc * K2B_PEND + 64) * sizeof(uint32_t);
+            const int syncD = opt.sync < 0 ? K2C_DEFAULT_SYNC : opt.sync;
+            // the scan's own lane mapping: whole 16 / 8 / 4-byte pieces per lane ("split") where the row decomposes that
+            // way (W = 1280, 1680, ...), the row machine's blocked mapping otherwise.  Measured with the v_sad_u8 scan,
+            // A/B on one box: trigger-only -12 % at W = 1280 and -6 % at 1680, store mode -13 % / -4 % (round 2)
             constexpr bool CAN_SPLIT = NDW >= 5 && NDW <= 7;
-            const bool split = CAN_SPLIT && opt.split && (diff != nullptr || NDW == 5 || opt.split > 1);
-#define K2C_ARGS frames, sigma6, jobs, L, S, nslot, W, H, R, nchunks, budget, units, counters, hist, diff, gl
-#define K2C_LAUNCH_SP(KK, ST, SP) hipLaunchKernelGGL((k2_bound_chain<NDW, KK, ST, SP>), grid, dim3(64), 0, st, K2C_ARGS)
-#define K2C_LAUNCH(KK, ST)                                                                                          \
-    if (split) {                                                                                                    \
-        K2C_LAUNCH_SP(KK, ST, CAN_SPLIT);                                                                           \
+            const bool split = CAN_SPLIT && opt.split;
+            // rows fetched two steps ahead (183 instead of 153 registers: 2 waves per SIMD, measured -2 % on the bench's
+            // trigger pass, equal in store mode): trigger-only at NDW = 5, K = 4 only
+            const bool pf2 = NDW == 5 && split && Kc == 4 && !diff && (opt.scanpf < 0 || opt.scanpf == 2);
+#define K2C_ARGS frames, sigma6, jobs, L, S, nwgs, W, H, R, nchunks, budget, units, counters, hist, diff, gl, syncD
+#define K2C_LAUNCH_SP(KK, ST, SP, PFD) \
+    hipLaunchKernelGGL((k2_sad_chain<NDW, KK, ST, SP, PFD>), grid, dim3(64 * NW), ldsBytes, st, K2C_ARGS)
+#define K2C_LAUNCH(KK)                                                                                              \
+    if (diff) {                                                                                                     \
+        if (split) {                                                                                                \
+            K2C_LAUNCH_SP(KK, true, CAN_SPLIT, 1);                                                                  \
+        } else {                                                                                                    \
+            K2C_LAUNCH_SP(KK, true, false, 1);                                                                      \
+        }                                                                                                           \
     } else {                                                                                                        \
-        K2C_LAUNCH_SP(KK, ST, false);                                                                               \
+        if (split) {                                                                                                \
+            K2C_LAUNCH_SP(KK, false, CAN_SPLIT, 1);                                                                 \
+        } else {                                                                                                    \
+            K2C_LAUNCH_SP(KK, false, false, 1);                                                                     \
+        }                                                                                                           \
     }
-            if (Kc == 3) {
-                if (diff) {
-                    K2C_LAUNCH(3, true);
-                } else {
-                    K2C_LAUNCH(3, false);
-                }
+            if (pf2) {
+                if constexpr (NDW == 5)
+                    K2C_LAUNCH_SP(4, false, true, 2);
+            } else if (Kc == 4) {
+                K2C_LAUNCH(4);
             } else {
-                if (diff) {
-                    K2C_LAUNCH(2, true);
-                } else {
-                    K2C_LAUNCH(2, false);
-                }
+                K2C_LAUNCH(2);
             }
 #undef K2C_LAUNCH_SP
 #undef K2C_ARGS

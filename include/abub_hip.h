@@ -125,14 +125,18 @@ int abub_diff_hist_chained_dev(const uint8_t *frames, const uint8_t *sigma6, con
 int abub_diff_hist_chained_store_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs, int njobs, int W,
                                      int H, uint32_t *hist, uint8_t *diff, int chain_len, int chain_stride, void *stream);
 
-/* Run-time tuning knobs of the K2 launchers (defaults from ABUB_K2_BOUND / _CHAIN / _BUDGET / _PF in the environment):
+/* Run-time tuning knobs of the K2 launchers (defaults from ABUB_K2_BOUND / _CHAIN / _BUDGET / _PF / _SPLIT / _LIST / _WG /
+ * _SYNC / _SCANPF in the environment):
  *   "bound"  1 = bound-and-verify pass (default), 0 = the plain row machine for every row (the dense-regime worst case)
- *   "chain"  jobs per wave of the chained scan: 2 or 3; 0 = never chain; -1 (default) = 3 for W <= 1280, else 2
- *   "split"  1 (default) = the chained scan's whole-piece lane mapping where it pays, 0 = never, 2 = wherever possible
+ *   "chain"  jobs per wave of the chained scan: 2 or 4 (>= 3 means 4); 0 = never chain; -1 (default) = 4
+ *   "split"  1 (default) = the chained scan's whole-piece lane mapping wherever the row width allows it, 0 = never
  *   "budget" suspect groups a (job, chunk) may list in LDS before it hands its remaining rows to the row machine
  *   "list"   1 = suspect groups go to a global list that a second kernel evaluates exactly with the whole chip;
  *            0 (default) = every scanning wave evaluates its own suspects at its end
  *   "pf"     software-prefetch depth of the row machine (1 or 2)
+ *   "scanpf" rows the chained scan fetches ahead: 1, 2, -1 (default) = 2 where instantiated (trigger-only, W = 1280 class)
+ *   "wg"     waves per workgroup of the chained scan = consecutive segments of one chain (1 .. 8; -1 default = 1)
+ *   "sync"   row steps a wave of such a workgroup may run ahead of its slowest wave (0 = never waits; -1 default = 0)
  * Results never depend on them. */
 int abub_k2_set_option(const char *name, int value);
 

@@ -20,6 +20,9 @@ def _k2_defaults():
     hip.k2_set_option("budget", 1024)
     hip.k2_set_option("split", 1)
     hip.k2_set_option("list", 0)
+    hip.k2_set_option("wg", -1)
+    hip.k2_set_option("sync", -1)
+    hip.k2_set_option("scanpf", -1)
 
 
 def rnd_frames(rs, n, H, W, base=None, amp=12):
@@ -90,6 +93,55 @@ def test_k2_extreme_values(oracle):
     assert np.array_equal(hist.cpu().numpy().astype(np.uint32), href)
     hist, _ = hip.diff_hist(f_d, s6, hip.make_jobs(jobs, DEV), W, H, store=False)  # trigger-only kernel
     assert np.array_equal(hist.cpu().numpy().astype(np.uint32), href)
+
+
+
+@pytest.mark.parametrize("W,H", [(1280, 40), (1680, 30), (512, 24)])
+def test_k2_chained_scan_decision_boundary_and_saturation(oracle, W, H):
+    """The chained scan (v_sad_u8 masses with HI = min(r + s, 255), LO = sat(r - s) taken from every other frame of the
+    chain) on inputs that sit on both sides of every decision: pixel values at 0 / 255 with
+    sigma6 from 0 to 255 (r + s and r - s saturate), isolated supra-threshold pixels of excess 1..5 and small clusters
+    (bound = 21 vs 22), at the image edges, in every lane segment; stride-1 and stride-2 chains of odd and even length.
+    Histograms and stored D must equal the oracle's for every jobs-per-wave / workgroup setting."""
+    rs = np.random.RandomState(W + 7 * H)
+    n = 11
+    base = rs.randint(0, 256, (H, W)).astype(np.int64)
+    base[:, : W // 8] = 0            # c, r at the low rail
+    base[:, W // 8: W // 4] = 255    # ... and at the high rail
+    frames = np.repeat(base[None], n, 0)
+    for f in range(n):
+        k = rs.randint(100, 500)
+        ys, xs = rs.randint(0, H, k), rs.randint(0, W, k)
+        frames[f, ys, xs] += rs.choice([-1, 1], k) * rs.randint(1, 7, k)
+        for _ in range(20):  # tight clusters whose masses cross the bound only together
+            y, x = rs.randint(0, H - 1), rs.randint(0, W - 2)
+            frames[f, y, x] += rs.randint(1, 4)
+            frames[f, y + rs.randint(0, 2), x + rs.randint(0, 3)] += rs.randint(1, 4)
+        for (y, x) in [(0, 0), (0, 1), (1, 0), (H - 1, W - 1), (H - 2, W - 1), (H - 1, W - 2), (0, W - 1), (H - 1, 0)]:
+            frames[f, y, x] += rs.randint(-6, 7)
+        if f % 3 == 2:  # large excursions: |c - r| up to 255
+            ys, xs = rs.randint(0, H, 60), rs.randint(0, W, 60)
+            frames[f, ys, xs] = rs.choice([0, 255], 60)
+    frames = np.clip(frames, 0, 255).astype(np.uint8)
+    sigma = np.zeros((2, H, W), np.uint8)
+    sigma[1] = rs.choice([0, 0, 1, 1, 2, 7, 20, 42, 43, 255], (H, W))  # sigma6 = 0 .. 252, 255 (saturated)
+    f_d = torch.from_numpy(frames).to(DEV)
+    s6 = hip.sigma6(torch.from_numpy(sigma).to(DEV))
+    for model in (0, 1):
+        for off in (1, 2):
+            jl = [(i, max(i - off, 0), model, i - 1) for i in range(1, n)]
+            Dref, href = oracle_hists(oracle, frames, sigma, jl)
+            jobs = hip.make_jobs(jl, DEV)
+            for pf, K, wg, sync in ((1, 4, 1, 0), (2, 4, 2, 1), (1, 2, 4, 0), (-1, -1, -1, -1)):
+                hip.k2_set_option("scanpf", pf)
+                hip.k2_set_option("chain", K)
+                hip.k2_set_option("wg", wg)
+                hip.k2_set_option("sync", sync)
+                hist, D = hip.diff_hist(f_d, s6, jobs, W, H, store=True, chain=(n - 1, off))
+                assert np.array_equal(hist.cpu().numpy().astype(np.uint32), href), (model, off, pf, K, wg, sync)
+                assert np.array_equal(D.cpu().numpy(), Dref), (model, off, pf, K, wg, sync)
+                hist, _ = hip.diff_hist(f_d, s6, jobs, W, H, store=False, chain=(n - 1, off))
+                assert np.array_equal(hist.cpu().numpy().astype(np.uint32), href), (model, off, pf, K, wg, sync)
 
 
 @pytest.mark.parametrize("H,W,R", [(96, 1280, 0), (70, 1680, 16), (40, 256, 8), (33, 2048, 0), (64, 100, 16)])
@@ -387,6 +439,16 @@ def test_k2_trigger_only_equals_store_mode_full_size(W, H):
     h_cstore, D_c = hip.diff_hist(fr, s6, jobs, W, H, store=True, chain=(F - 1, 2))  # chained scan, store mode
     hip.k2_set_option("chain", 3)
     h_c3, D_c3 = hip.diff_hist(fr, s6, jobs, W, H, store=True, chain=(F - 1, 2))
+    # workgroups of several waves on one chain, with and without the soft sync; one or two rows fetched ahead
+    for wg, sync, pf, K in ((4, 2, 1, 4), (2, 0, 2, 4), (1, 0, 1, 2), (4, 2, 2, 4), (1, 0, -1, -1)):
+        hip.k2_set_option("wg", wg)
+        hip.k2_set_option("sync", sync)
+        hip.k2_set_option("scanpf", pf)
+        hip.k2_set_option("chain", K)
+        h_w, D_w = hip.diff_hist(fr, s6, jobs, W, H, store=True, chain=(F - 1, 2))
+        h_wt, _ = hip.diff_hist(fr, s6, jobs, W, H, store=False, chain=(F - 1, 2))
+        assert torch.equal(h_w, h_c3) and torch.equal(D_w, D_c3) and torch.equal(h_wt, h_c3), (wg, sync, pf, K)
+    hip.k2_set_option("chain", 3)
     hip.k2_set_option("list", 1)  # suspects through the global list and sus_tail_list instead of the in-wave tails
     h_l1, D_l1 = hip.diff_hist(fr, s6, jobs, W, H, store=True, chain=(F - 1, 2))
     h_l1t, _ = hip.diff_hist(fr, s6, jobs, W, H, store=False)
@@ -433,18 +495,26 @@ def test_k2_chained_trigger_pass(oracle, W, H, F, off):
     Dref, _ = oracle_hists(oracle, frames, sigma, [tuple(r) for r in jn])
     # chain = jobs per wave; split = the scan's lane mapping (whole 16/8/4-byte pieces per lane where the width allows
     # it -- 1280 {4,1}, 1400 {4,2}, 1540 / 1680 / 1792 {4,2,1}, 1100 {4,1} with a partial last segment -- or blocked)
-    for K, split, lst in ((2, 2, 1), (3, 2, 1), (2, 0, 1), (-1, 1, 1), (3, 2, 0), (2, 0, 0)):
+    # wg = waves per workgroup (consecutive segments of one chain, DESIGN.md "chained scan"), sync = row steps a wave may run
+    # ahead of its workgroup's slowest wave (0: never waits)
+    # pf = rows the chained scan fetches ahead (2 exists for the split mapping at 5 dwords per lane; -1 = automatic)
+    for K, split, lst, wg, sync, pf in ((2, 1, 1, 1, 0, 1), (4, 1, 1, 4, 2, 1), (2, 0, 1, 2, 1, 1), (-1, 1, 1, 4, 0, 2),
+                                        (4, 1, 0, 3, 4, 2), (2, 0, 0, 4, 1, -1), (-1, 1, 0, -1, -1, -1), (4, 1, 0, 2, 2, 1),
+                                        (4, 0, 1, 1, 0, -1)):
+        hip.k2_set_option("scanpf", pf)
         hip.k2_set_option("chain", K)
         hip.k2_set_option("split", split)
         hip.k2_set_option("list", lst)  # 0: the scanning waves evaluate their suspects themselves
+        hip.k2_set_option("wg", wg)
+        hip.k2_set_option("sync", sync)
         for L, S in [(F - 1, off), (F - 1, off + 1), (F - 1, 1), ((F - 1) * nst, off), (1, 1)]:
             if ((F - 1) * nst) % L:
                 continue
             got, _ = hip.diff_hist(f_d, s6, jobs, W, H, chain=(L, S))
-            assert torch.equal(got, plain), (K, split, lst, L, S)
+            assert torch.equal(got, plain), (K, split, lst, wg, sync, pf, L, S)
             got, D = hip.diff_hist(f_d, s6, jobs, W, H, chain=(L, S), store=True)
-            assert torch.equal(got, plain), (K, split, lst, L, S)
-            assert np.array_equal(D.cpu().numpy(), Dref), (K, split, lst, L, S)
+            assert torch.equal(got, plain), (K, split, lst, wg, sync, pf, L, S)
+            assert np.array_equal(D.cpu().numpy(), Dref), (K, split, lst, wg, sync, pf, L, S)
 
 
 def test_scratch_release_and_reuse():

@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 template <int W, int MAP>
@@ -331,6 +332,93 @@ __global__ __launch_bounds__(256) void copy_flat(const uint4 *__restrict__ src, 
         dst[i] = src[i];
 }
 
+// The copy in the shape MI355X_MICROARCH.md quotes for its 6.29 TB/s figure: UNR independent 16-byte loads per lane in flight
+// before the first store, a grid of a few waves per SIMD striding over contiguous UNR x 4 KiB tiles.  NT bit 0:
+// nontemporal loads, bit 1: nontemporal stores.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int UNR, int NT>
+__global__ __launch_bounds__(256) void copy_guide(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, size_t n16)
+{
+    const size_t tile = (size_t)UNR * 256;
+    for (size_t base = (size_t)blockIdx.x * tile; base + tile <= n16; base += (size_t)gridDim.x * tile) {
+        u32x4 v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; u++)
+            v[u] = (NT & 1) ? __builtin_nontemporal_load(&src[base + (size_t)u * 256 + threadIdx.x]) : src[base + (size_t)u * 256 + threadIdx.x];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            if (NT & 2)
+                __builtin_nontemporal_store(v[u], &dst[base + (size_t)u * 256 + threadIdx.x]);
+            else
+                dst[base + (size_t)u * 256 + threadIdx.x] = v[u];
+        }
+    }
+}
+// write-only and read-only streams in the same shape (what each direction gives alone)
+template <int UNR, int NT>
+__global__ __launch_bounds__(256) void fill_guide(u32x4 *__restrict__ dst, size_t n16)
+{
+    const size_t tile = (size_t)UNR * 256;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (size_t base = (size_t)blockIdx.x * tile; base + tile <= n16; base += (size_t)gridDim.x * tile) {
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            if (NT & 2)
+                __builtin_nontemporal_store(z, &dst[base + (size_t)u * 256 + threadIdx.x]);
+            else
+                dst[base + (size_t)u * 256 + threadIdx.x] = z;
+        }
+    }
+}
+template <int UNR>
+__global__ __launch_bounds__(256) void read_guide(const u32x4 *__restrict__ src, size_t n16, uint32_t *__restrict__ out)
+{
+    const size_t tile = (size_t)UNR * 256;
+    u32x4 acc = {0u, 0u, 0u, 0u};
+    for (size_t base = (size_t)blockIdx.x * tile; base + tile <= n16; base += (size_t)gridDim.x * tile) {
+        u32x4 v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; u++)
+            v[u] = src[base + (size_t)u * 256 + threadIdx.x];
+#pragma unroll
+        for (int u = 0; u < UNR; u++)
+            acc ^= v[u];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u)
+        out[0] = 1;
+}
+
+static void copy_ceiling(const uint8_t *slab, uint8_t *diff, uint32_t *out, int F)
+{
+    const size_t n16 = (size_t)1280 * 1024 * F / 16 / 2048 * 2048;
+    const double GB = n16 * 16 / 1e9;
+#define CG(UNR, NT, BLOCKS)                                                                                                     \
+    {                                                                                                                           \
+        float ms = timeit([&] { hipLaunchKernelGGL((copy_guide<UNR, NT>), dim3(BLOCKS), dim3(256), 0, 0, (const u32x4 *)slab, (u32x4 *)diff, n16); }, 5); \
+        printf("{\"pattern\": \"guide copy\", \"loads_in_flight\": %d, \"nt\": %d, \"blocks\": %d, \"GB_read\": %.2f, \"ms\": %.4f, \"TBps_read_plus_write\": %.3f}\n", UNR, NT, BLOCKS, GB, ms, 2 * GB / ms); \
+    }
+    CG(4, 0, 1024) CG(4, 0, 2048) CG(4, 0, 4096) CG(4, 0, 8192) CG(4, 0, 16384)
+    CG(8, 0, 1024) CG(8, 0, 2048) CG(8, 0, 4096)
+    CG(2, 0, 4096) CG(1, 0, 8192)
+    CG(4, 2, 1024) CG(4, 2, 2048) CG(4, 2, 4096) CG(4, 2, 8192)
+    CG(4, 1, 2048) CG(4, 3, 2048) CG(4, 3, 4096) CG(8, 3, 2048) CG(8, 2, 2048)
+#undef CG
+    for (int blocks : {2048, 4096}) {
+        float ms = timeit([&] { hipLaunchKernelGGL((fill_guide<4, 0>), dim3(blocks), dim3(256), 0, 0, (u32x4 *)diff, n16); }, 5);
+        printf("{\"pattern\": \"guide fill\", \"nt\": 0, \"blocks\": %d, \"GB\": %.2f, \"ms\": %.4f, \"TBps\": %.3f}\n", blocks, GB, ms, GB / ms);
+        ms = timeit([&] { hipLaunchKernelGGL((fill_guide<4, 2>), dim3(blocks), dim3(256), 0, 0, (u32x4 *)diff, n16); }, 5);
+        printf("{\"pattern\": \"guide fill\", \"nt\": 2, \"blocks\": %d, \"GB\": %.2f, \"ms\": %.4f, \"TBps\": %.3f}\n", blocks, GB, ms, GB / ms);
+        ms = timeit([&] { hipLaunchKernelGGL((read_guide<4>), dim3(blocks), dim3(256), 0, 0, (const u32x4 *)slab, n16, out); }, 5);
+        printf("{\"pattern\": \"guide read\", \"blocks\": %d, \"GB\": %.2f, \"ms\": %.4f, \"TBps\": %.3f}\n", blocks, GB, ms, GB / ms);
+    }
+    {
+        float ms = timeit([&] { CK(hipMemcpyAsync(diff, slab, n16 * 16, hipMemcpyDeviceToDevice, 0)); }, 5);
+        printf("{\"pattern\": \"hipMemcpy D2D\", \"GB_read\": %.2f, \"ms\": %.4f, \"TBps_read_plus_write\": %.3f}\n", GB, ms, 2 * GB / ms);
+        ms = timeit([&] { CK(hipMemsetAsync(diff, 0, n16 * 16, 0)); }, 5);
+        printf("{\"pattern\": \"hipMemset\", \"GB\": %.2f, \"ms\": %.4f, \"TBps\": %.3f}\n", GB, ms, GB / ms);
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int F = argc > 1 ? atoi(argv[1]) : 2000, R = argc > 2 ? atoi(argv[2]) : 0;
@@ -345,6 +433,10 @@ int main(int argc, char **argv)
     CK(hipMemset(sg, 2, Pmax));
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
+    if (argc > 3 && !strcmp(argv[3], "copy")) { // only the chip's copy / fill / read ceilings
+        copy_ceiling(slab, diff, out, F);
+        return 0;
+    }
     {
         const int H = 1024, Rr = R > 0 ? R : 128, nch = (H + Rr - 1) / Rr, njobs = F - 2, nchains = (njobs / 4) * 2;
 #define OCCRUN(MAP, OCC, VALU)                                                                                                   \
