@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void sus_tail_list(const uint8_t *__restrict__
                     }
                     c += COMPACT && (int)v > thr[u];
                 }
-                if (STORE) // (the scan wrote this row as zeros; an aligned dword)
+                if (STORE) // (the launcher cleared the image; an aligned dword)
                     *reinterpret_cast<uint32_t *>(img + (size_t)jb.out * P + (size_t)y * W + x0) = packed;
                 Ov[u] = packed;
                 pix0[u] = (uint32_t)(y * W + x0);

@@ -304,7 +304,7 @@ struct K3ScanJob {
 };
 
 // the wave's own tail (no global list, or it is full): one lane per remembered group
-template <bool COMPACT, bool STORE>
+template <bool COMPACT>
 __device__ __forceinline__ void k3s_tail(const uint32_t *pend, uint32_t npend, const abub_job jb, const uint8_t *__restrict__ frames,
                                          const uint8_t *__restrict__ mu, const uint8_t *__restrict__ sigma6, int W, int H,
                                          uint32_t *__restrict__ hist, uint8_t *__restrict__ img, const Compact &cp, int lane)
@@ -331,7 +331,7 @@ __device__ __forceinline__ void k3s_tail(const uint32_t *pend, uint32_t npend, c
                 if (v)
                     atomicAdd(&hist[(size_t)jb.out * 256 + v], 1u);
             }
-            if (STORE)
+            if (img) // (the launcher cleared the image)
                 *reinterpret_cast<uint32_t *>(img + (size_t)jb.out * P + (size_t)y * W + x0) = packed;
             pix0 = (uint32_t)(y * W + x0);
         }
@@ -348,7 +348,7 @@ __device__ __forceinline__ void k3s_tail(const uint32_t *pend, uint32_t npend, c
     }
 }
 
-template <int NDW, int KF, bool STORE, bool COMPACT>
+template <int NDW, int KF, bool COMPACT>
 __global__ __launch_bounds__(64) void k3_bound_scan(const uint8_t *__restrict__ frames, const uint8_t *__restrict__ mu,
                                                     const uint8_t *__restrict__ sigma6,
                                                     const abub_job *__restrict__ jobs, int njobs, int W, int H,
@@ -396,12 +396,10 @@ __global__ __launch_bounds__(64) void k3_bound_scan(const uint8_t *__restrict__ 
     const uint8_t *m = mu + (size_t)jb[0].model * P;
     const uint8_t *sg = sigma6 + (size_t)jb[0].model * P;
     const uint8_t *f[KF];
-    uint8_t *obase[KF];
     K3ScanJob<NDW> J[KF];
 #pragma unroll
     for (int t = 0; t < KF; t++) {
         f[t] = frames + (size_t)jb[t].cur * P;
-        obase[t] = STORE ? img + (size_t)jb[t].out * P + xoff : nullptr;
 #pragma unroll
         for (int g = 0; g < NG; g++)
             J[t].Mh[0][g] = J[t].Mh[1][g] = 0;
@@ -524,13 +522,6 @@ __global__ __launch_bounds__(64) void k3_bound_scan(const uint8_t *__restrict__ 
                         J[t].npend = base;
                     }
                 }
-                if (STORE && emit && y >= J[t].skipTo && active) {
-                    // the scan is responsible for this row: zeros now, the tail overwrites its suspect groups
-                    uint32_t *po = reinterpret_cast<uint32_t *>(obase[t] + (ptrdiff_t)y * W);
-#pragma unroll
-                    for (int d = 0; d < NDW; d++)
-                        po[d] = 0;
-                }
             }
         }
     }
@@ -564,7 +555,7 @@ __global__ __launch_bounds__(64) void k3_bound_scan(const uint8_t *__restrict__ 
             cp.cap = pcap;
             cp.slot = jb[t].out + slot_base;
             cp.thr = COMPACT ? cthr[jb[t].out] : 255;
-            k3s_tail<COMPACT, STORE>(pend[t], J[t].npend, jb[t], frames, mu, sigma6, W, H, hist, img, cp, lane);
+            k3s_tail<COMPACT>(pend[t], J[t].npend, jb[t], frames, mu, sigma6, W, H, hist, img, cp, lane);
         }
     }
 }
@@ -622,13 +613,17 @@ static int launch_k3_rows(const uint8_t *frames, const uint8_t *mu, const uint8_
         }
         const uint32_t k3budget = (uint32_t)k3b;
 #define K3S_LAUNCH(ST, CO)                                                                                          \
-    hipLaunchKernelGGL((k3_bound_scan<NDW, KF, ST, CO>), sgrid, dim3(64), 0, st, frames, mu, sigma6, jobs, njobs, W, \
-                       H, R, nchunks, hist, img, pieces, counter, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base, \
+    hipLaunchKernelGGL((k3_bound_scan<NDW, KF, CO>), sgrid, dim3(64), 0, st, frames, mu, sigma6, jobs, njobs, W, H, R,  \
+                       nchunks, hist, img, pieces, counter, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base,      \
                        k3budget, glist, gcount, (uint32_t)gcap);                                                    \
     if (glist)                                                                                                      \
     hipLaunchKernelGGL((sus_tail_list<3, CO, ST>), dim3(tgrid), dim3(256), 0, st, frames, mu, sigma6, jobs, W, H, hist, \
                        img, glist, gcount, (uint32_t)gcap, ca.cthr, ca.pairs, ca.cap, ca.count, ca.slot_base)
         const unsigned tgrid = (unsigned)((gcap + 256 * SUSL_UB - 1) / (256 * SUSL_UB) < 2048 ? (gcap + 256 * SUSL_UB - 1) / (256 * SUSL_UB) : 2048);
+        // store mode: the images are cleared first (a pure write stream at the chip's fill rate); only the exact tails
+        // and the row machine write pixels afterwards.  (Contract, as for `hist`: output slots 0 .. njobs - 1.)
+        if (img)
+            HIPCHK(hipMemsetAsync(img, 0, (size_t)njobs * (size_t)W * (size_t)H, st));
         if (ca.cthr) {
             if (img) {
                 K3S_LAUNCH(true, true);

@@ -144,7 +144,7 @@ int main(int argc, char **argv)
     double ms = sum / reps;
     // compulsory bytes: every frame once (+ D once in store mode); the contract's algorithmic figure charges cur, ref, sigma6
     double bytes = (store ? 4.0 : 3.0) * P * njobs, comp = (store ? 2.0 : 1.0) * P * njobs;
-    printf("{\"frames\": %d, \"W\": %d, \"H\": %d, \"store\": %d, \"chain\": %d, \"sigma\": %d, \"ms_avg\": %.4f, \"ms_min\": %.4f, "
+    printf("{\"frames\": %d, \"W\": %d, \"H\": %d, \"store\": %d, \"chain\": %d, \"sigma\": %d, \"cycle\": %d, \"ms_avg\": %.4f, \"ms_min\": %.4f, "
            "\"frames_per_s\": %.1f, \"compulsory_GBps\": %.1f, \"frac_of_8TBps\": %.4f, \"alg_GBps\": %.1f, \"nonzero_px\": %llu, "
            "\"hist_total_ok\": %d}\n",
            njobs, W, H, store, chain, sig, cyc, ms, best, njobs / (ms * 1e-3), comp / (ms * 1e-3) / 1e9, comp / (ms * 1e-3) / 1e9 / 8000.0,
