@@ -41,9 +41,13 @@ SIGNATURES = {
     "abub_fg_compact_dev": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "abub_fast_path": (_i, [_i]),
     "abub_scratch_release": (_i, [_vp]),
+    "abub_bound_counts_dev": (_i, [_vp, C.POINTER(C.c_uint32)]),
     "abub_diff_hist_chained_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "abub_diff_hist_chained_store_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "abub_k2_set_option": (_i, [C.c_char_p, _i]),
+    "abub_k2_pieces_cap": (_sz, [_i, _i, _i]),
+    "abub_diff_hist_chained_deferred_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, C.c_uint32, _vp, _vp, _vp]),
+    "abub_diff_hist_pieces_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "abub_diff_hist_compact_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp]),
     "abub_posttrig_compact_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp]),
     "abub_pairs_group_dev": (_i, [_vp, _vp, C.c_uint32, _i, _vp, _vp, _vp, _vp, _vp]),

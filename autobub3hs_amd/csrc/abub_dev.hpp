@@ -79,8 +79,10 @@ __device__ __forceinline__ uint32_t widen_lo(uint32_t w) { return __builtin_amdg
 __device__ __forceinline__ uint32_t widen_hi(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c030c02u); }
 
 // hist[slot][0] = P - sum(hist[slot][1..255])  (the kernels only count non-zero pixels)
-static __global__ __launch_bounds__(64) void k_hist_bin0(uint32_t *hist, uint32_t P)
+static __global__ __launch_bounds__(64) void k_hist_bin0(uint32_t *hist, uint32_t P, const uint8_t *__restrict__ only = nullptr)
 {
+    if (only && !only[blockIdx.x]) // (deferred pieces: only the slots whose rows were just completed)
+        return;
     uint32_t *h = hist + (size_t)blockIdx.x * 256;
     int l = threadIdx.x;
     uint32_t s = h[l + 64] + h[l + 128] + h[l + 192] + (l ? h[l] : 0u);
@@ -170,14 +172,17 @@ __device__ __forceinline__ void compact_put(const Compact &cp, uint32_t &pos, ui
 
 // hand the rows [y, y1) of `unit` to the row machine, in pieces of K2B_SUB rows (capacity: see launch_k2_rows)
 __device__ __forceinline__ void k2b_hand_over(uint2 *__restrict__ units, uint32_t *__restrict__ nunits, uint32_t unit, int y, int y1,
-                                              int lane)
+                                              int lane, uint8_t *__restrict__ incomplete = nullptr, uint32_t job = 0)
 {
     const int np = (y1 - y + K2B_SUB - 1) / K2B_SUB;
     if (np <= 0)
         return;
     uint32_t base = 0;
-    if (lane == 0)
+    if (lane == 0) {
         base = atomicAdd(nunits, (uint32_t)np);
+        if (incomplete) // deferred pieces (abub_diff_hist_chained_deferred_dev): the job's histogram is not final yet
+            incomplete[job] = 1;
+    }
     base = __builtin_amdgcn_readfirstlane(base);
     for (int i = lane; i < np; i += 64) {
         const int a = y + i * K2B_SUB, b = a + K2B_SUB < y1 ? a + K2B_SUB : y1;
@@ -499,4 +504,10 @@ struct CompactArgs {
     uint32_t *count;
     uint32_t slot_base; // added to job.out in the list entries (several launches share one list)
     int chain_len = 0, chain_stride = 0; // trigger-only hint: blocks of chain_len jobs, job q refs the cur of job q - stride
+    // deferred pieces (trigger-only): the handed-over row ranges go to the CALLER's list instead of the row machine, and
+    // incomplete[job] is set for every job that has some; abub_diff_hist_pieces_dev() evaluates them later, per job
+    uint2 *df_pieces = nullptr;
+    uint32_t df_cap = 0;
+    uint32_t *df_count = nullptr;
+    uint8_t *df_incomplete = nullptr;
 };

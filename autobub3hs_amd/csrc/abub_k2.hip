@@ -206,7 +206,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER
                                               const int32_t *__restrict__ cthr, uint32_t *pairs,
                                               uint32_t pcap, uint32_t *pcount, uint32_t slot_base,
                                               const uint2 *__restrict__ unit_list,
-                                              const uint32_t *__restrict__ unit_count)
+                                              const uint32_t *__restrict__ unit_count,
+                                              const uint8_t *__restrict__ want = nullptr)
 {
     constexpr int NP = 2 * NDW; // u16-pair registers per plane per lane
     __shared__ uint32_t lh[256];
@@ -217,6 +218,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K2_WAVES_PER
     for (uint32_t ui = blockIdx.x; ui < nunits_; ui += gridDim.x) {
     const int unit = unit_list ? (int)unit_list[ui].x : (int)ui;
     const int job = unit / nchunks;
+    if (want && !want[job]) // deferred pieces: only the jobs the trigger search actually reached (workgroup-uniform)
+        continue;
     const int chunk = unit - job * nchunks; // chunk fastest: unit % 8 == chunk % 8 when nchunks % 8 == 0
     const abub_job jb = jobs[job];
     const size_t P = (size_t)W * H;
@@ -420,6 +423,7 @@ struct K2BoundJob { // per-job state of the bound recurrence and of its suspect 
     uint32_t P[4][CASC ? 2 : 1][NG];
     uint32_t Mp[PLAINM ? 2 : 1][NG]; // PLAIN, in-place form: M of the previous row, by row parity (nothing is copied)
     uint32_t npend, hot, jidx;
+    uint32_t mark; // npend when the current streak of dense rows began (hot = its length)
     int handover; // < 0: scanning; >= 0: first output row left to the row machine (or "nothing to do")
 };
 
@@ -494,8 +498,10 @@ __device__ __forceinline__ void k2b_row(JOB &J, const int par, uint32_t (&m)[NDW
         worst = JOB::PLAIN ? (B[g] > worst ? B[g] : worst) : (worst | B[g]);
     }
     const bool unsure = act && JOB::over(worst); // 6 * mass < 128 <=> mass <= 21 (packed: lo + hi; plain: twice the mass <= 42)
-    if (!(emit && __builtin_amdgcn_ballot_w64(unsure)))
+    if (!(emit && __builtin_amdgcn_ballot_w64(unsure))) {
+        J.hot = 0; // (a quiet row ends a streak of dense ones)
         return;
+    }
     // ---- rare: some group of this row cannot be proven zero -----------------------------------------------
     unsigned long long bm[NG]; // lanes whose recurrence group g (GS 4-pixel groups) is suspect
     bool mine[NG];
@@ -507,12 +513,26 @@ __device__ __forceinline__ void k2b_row(JOB &J, const int par, uint32_t (&m)[NDW
         const int nq = GS * g + GS <= NDW ? GS : NDW - GS * g; // 4-pixel groups of this recurrence group
         total += (uint32_t)nq * (uint32_t)__builtin_popcountll(bm[g]);
     }
-    J.hot += total > 32u; // one row of the row machine costs about as much as 30 exact groups
+    // One row of the row machine costs about as much as 30 exact groups.  Four dense rows in a row: the chunk is handed
+    // over FROM THE FIRST OF THEM, and what the streak put on the list is dropped again -- a dense frame then costs its
+    // scanning wave a few rows and no exact tail at all (round 2 kept the streak's groups: ~450 exact groups per chunk of
+    // every dense frame, whether anybody ever looked at that frame or not).
+    if (total > 32u) {
+        if (J.hot == 0)
+            J.mark = J.npend;
+        ++J.hot;
+    } else
+        J.hot = 0;
+    if (J.hot >= 4u) {
+        J.handover = y - 3;
+        J.npend = J.mark;
+        return;
+    }
     // (A full LDS list means a chunk with a lot of structure: for K2 the row machine is the cheaper way through such
     // rows -- an exact group costs 45 window loads and two 5x5 sums --, so the list is NOT flushed to the global suspect
     // list to make room, as K3 does; measured: flushing made the tail kernel 2.4x longer than the pieces it saved.)
-    if (J.hot >= 4u || J.npend + total > budget) {
-        J.handover = y; // dense rows (or the LDS list is full): the rest of the chunk goes to the row machine
+    if (J.npend + total > budget) {
+        J.handover = y; // the LDS list is full: the rest of the chunk goes to the row machine
         return;
     }
     uint32_t base = J.npend;
@@ -595,7 +615,8 @@ __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ 
                                                     uint2 *__restrict__ units, uint32_t *__restrict__ nunits,
                                                     uint32_t *__restrict__ hist, uint8_t *__restrict__ diff,
                                                     const int32_t *__restrict__ cthr, uint32_t *pairs, uint32_t pcap,
-                                                    uint32_t *pcount, uint32_t slot_base, SusList gl)
+                                                    uint32_t *pcount, uint32_t slot_base, SusList gl,
+                                                    uint8_t *__restrict__ incomplete)
 {
     constexpr int NP = 2 * NDW;
     __shared__ uint32_t pend[K2B_PEND];
@@ -651,7 +672,7 @@ __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ 
         }
     }
     if (J.handover >= 0)
-        k2b_hand_over(units, nunits, (uint32_t)unit, J.handover, y1, lane);
+        k2b_hand_over(units, nunits, (uint32_t)unit, J.handover, y1, lane, incomplete, (uint32_t)job);
     if (J.npend) { // the suspects go to the launch's global list; if that is full the wave evaluates them itself
         wave_lds_fence();
         uint32_t gb = 0;
@@ -722,7 +743,7 @@ __global__ __launch_bounds__(64 * K2C_MAXW) void k2_sad_chain(const uint8_t *__r
                                                    int H, int rows_per_chunk, int nchunks, uint32_t budget,
                                                    uint2 *__restrict__ units, uint32_t *__restrict__ nunits,
                                                    uint32_t *__restrict__ hist, uint8_t *__restrict__ diff, SusList gl,
-                                                   int syncD)
+                                                   int syncD, uint8_t *__restrict__ incomplete)
 {
     using Job = K2BoundJob<NDW, false, true>;
     // dynamic LDS: [NW][K][K2B_PEND] suspect lists (one set per wave), then [NW] progress words.  Progress word of a wave =
@@ -779,7 +800,8 @@ __global__ __launch_bounds__(64 * K2C_MAXW) void k2_sad_chain(const uint8_t *__r
 #pragma unroll
         for (int t = 0; t < K; t++)
             if (t < k)
-                k2b_hand_over(units, nunits, (jidx0 + (uint32_t)(S * t)) * (uint32_t)nchunks + (uint32_t)chunk, y0, y1, lane);
+                k2b_hand_over(units, nunits, (jidx0 + (uint32_t)(S * t)) * (uint32_t)nchunks + (uint32_t)chunk, y0, y1, lane, incomplete,
+                              jidx0 + (uint32_t)(S * t));
         K2C_PUBLISH(0x7fffffff);
         return;
     }
@@ -899,7 +921,8 @@ __global__ __launch_bounds__(64 * K2C_MAXW) void k2_sad_chain(const uint8_t *__r
     for (int t = 0; t < K; t++) {
         if (t < k) {
             if (J[t].handover >= 0)
-                k2b_hand_over(units, nunits, (jidx0 + (uint32_t)(S * t)) * (uint32_t)nchunks + (uint32_t)chunk, J[t].handover, y1, lane);
+                k2b_hand_over(units, nunits, (jidx0 + (uint32_t)(S * t)) * (uint32_t)nchunks + (uint32_t)chunk, J[t].handover, y1, lane,
+                              incomplete, jidx0 + (uint32_t)(S * t));
             tot += J[t].npend;
         }
     }
@@ -1125,6 +1148,16 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
             return set_err(ABUB_E_HIP, "abub_diff_hist_dev: scratch allocation failed");
         uint32_t *counters = (uint32_t *)scr; // [0] = handed-over pieces, [32] = entries of the global suspect list
         uint2 *units = (uint2 *)(scr + 256);
+        uint32_t *npieces = counters;
+        const bool deferred = ca.df_pieces != nullptr;
+        if (deferred) { // the pieces go to the caller's list; the row machine is not launched here
+            if (diff || ca.cthr || !ca.df_count || !ca.df_incomplete || (size_t)ca.df_cap < unitCap)
+                return set_err(ABUB_E_INVALID, "deferred pieces: trigger-only launches with a list of abub_k2_pieces_cap() entries");
+            units = ca.df_pieces;
+            npieces = ca.df_count;
+            HIPCHK(hipMemsetAsync(npieces, 0, sizeof(uint32_t), st));
+            HIPCHK(hipMemsetAsync(ca.df_incomplete, 0, (size_t)njobs, st));
+        }
         SusList gl;
         gl.list = gcap ? (uint2 *)(scr + 256 + unitBytes) : nullptr;
         gl.count = counters + 32;
@@ -1154,7 +1187,7 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
             // rows fetched two steps ahead (183 instead of 153 registers: 2 waves per SIMD, measured -2 % on the bench's
             // trigger pass): NDW = 5, K = 4 with the split mapping only
             const bool pf2 = NDW == 5 && split && Kc == 4 && (opt.scanpf < 0 || opt.scanpf == 2);
-#define K2C_ARGS frames, sigma6, jobs, L, S, nwgs, W, H, R, nchunks, budget, units, counters, hist, diff, gl, syncD
+#define K2C_ARGS frames, sigma6, jobs, L, S, nwgs, W, H, R, nchunks, budget, units, npieces, hist, diff, gl, syncD, ca.df_incomplete
 #define K2C_LAUNCH_SP(KK, SP, PFD) \
     hipLaunchKernelGGL((k2_sad_chain<NDW, KK, SP, PFD>), grid, dim3(64 * NW), ldsBytes, st, K2C_ARGS)
 #define K2C_LAUNCH(KK)                                                                                              \
@@ -1177,8 +1210,8 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
         } else {
 #define K2S_LAUNCH(CO)                                                                                              \
     hipLaunchKernelGGL((k2_bound_scan<NDW, CO>), dim3((unsigned)nunits), dim3(64), 0, st, frames, sigma6, jobs, W, H, \
-                       R, nchunks, budget, units, counters, hist, diff, ca.cthr, ca.pairs, ca.cap, ca.count,        \
-                       ca.slot_base, gl)
+                       R, nchunks, budget, units, npieces, hist, diff, ca.cthr, ca.pairs, ca.cap, ca.count,         \
+                       ca.slot_base, gl, ca.df_incomplete)
             if (ca.cthr) {
                 K2S_LAUNCH(true);
             } else {
@@ -1209,6 +1242,8 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
         }
         // the handed-over row ranges through the row machine's list mode (grid-stride over the pieces); with the fused
         // candidate list (cthr) it emits the candidates, with `diff` it writes its rows
+        if (deferred)
+            return ABUB_OK;
         const unsigned g3 = (unsigned)(unitCap < 4096 ? unitCap : 4096);
 #define K2R_LAUNCH(ST, CO)                                                                                          \
     hipLaunchKernelGGL((k2_rows<NDW, ST, 1, CO>), dim3(g3), dim3(64), 0, st, frames, sigma6, jobs, W, H, R, nchunks, \
@@ -1236,6 +1271,28 @@ static int launch_k2_rows(const uint8_t *frames, const uint8_t *sigma6, const ab
     return ABUB_OK;
 }
 
+// automatic rows per chunk of a launch of `njobs` jobs
+static int k2_auto_rows(int njobs, int H)
+{
+    // many jobs: 8 chunks per frame (<= ~3% vertical halo re-reads, chunk id == XCD id);
+    // fewer jobs: more, shorter chunks so that the launch still offers >= ~8k waves to the chip
+    int nch = 8;
+    if ((long long)njobs * nch < 8192)
+        nch = (8192 + njobs - 1) / njobs;
+    static int k2chunks = -1;
+    if (k2chunks < 0) {
+        const char *e = getenv("ABUB_K2_CHUNKS"); // tuning knob: chunks per frame (0 = automatic)
+        k2chunks = e ? atoi(e) : 0;
+    }
+    if (k2chunks > 0)
+        nch = k2chunks;
+    nch = (nch + 7) / 8 * 8; // keep chunk id == XCD id
+    int R = (H + nch - 1) / nch;
+    if (R < 16)
+        R = 16;
+    return R;
+}
+
 static int diff_hist_impl(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs, int njobs,
                           int W, int H, uint32_t *hist, uint8_t *diff, int rows_per_chunk,
                           const CompactArgs &ca, void *stream)
@@ -1250,25 +1307,7 @@ static int diff_hist_impl(const uint8_t *frames, const uint8_t *sigma6, const ab
     HIPCHK(hipMemsetAsync(hist, 0, (size_t)njobs * 256 * sizeof(uint32_t), st));
     int ndw = pick_ndw(W);
     if (ndw) {
-        int R = rows_per_chunk;
-        if (R == 0) {
-            // many jobs: 8 chunks per frame (<= ~3% vertical halo re-reads, chunk id == XCD id);
-            // fewer jobs: more, shorter chunks so that the launch still offers >= ~8k waves to the chip
-            int nch = 8;
-            if ((long long)njobs * nch < 8192)
-                nch = (8192 + njobs - 1) / njobs;
-            static int k2chunks = -1;
-            if (k2chunks < 0) {
-                const char *e = getenv("ABUB_K2_CHUNKS"); // tuning knob: chunks per frame (0 = automatic)
-                k2chunks = e ? atoi(e) : 0;
-            }
-            if (k2chunks > 0)
-                nch = k2chunks;
-            nch = (nch + 7) / 8 * 8; // keep chunk id == XCD id
-            R = (H + nch - 1) / nch;
-            if (R < 16)
-                R = 16;
-        }
+        const int R = rows_per_chunk ? rows_per_chunk : k2_auto_rows(njobs, H);
         int nchunks = (H + R - 1) / R;
         int rc = ABUB_OK;
         switch (ndw) {
@@ -1329,6 +1368,78 @@ extern "C" int abub_diff_hist_chained_store_dev(const uint8_t *frames, const uin
     ca.chain_len = chain_len;
     ca.chain_stride = chain_stride;
     return diff_hist_impl(frames, sigma6, jobs, njobs, W, H, hist, diff, 0, ca, stream);
+}
+
+// ---- deferred pieces ------------------------------------------------------------------------------------------------
+// The trigger search of a stack stops at its trigger frame (AnalyzerUnit.cpp:191, break at :307), but a batched launch
+// evaluates whole blocks of frames before the host knows where that is.  The bound scan is cheap on dense frames (a chunk
+// that keeps exceeding its suspect budget hands its remaining rows over and stops); the row machine on those rows is not.
+// So the scan can leave the handed-over row ranges in a caller-owned list and only FLAG the jobs that have some; the host
+// runs the row machine later, and only for the jobs its state machines actually reach.
+extern "C" size_t abub_k2_pieces_cap(int njobs, int W, int H)
+{
+    if (njobs <= 0 || H <= 0)
+        return 0;
+    const int R = k2_auto_rows(njobs, H), nchunks = (H + R - 1) / R;
+    return (size_t)njobs * nchunks * (size_t)((R + K2B_SUB - 1) / K2B_SUB);
+}
+
+extern "C" int abub_diff_hist_chained_deferred_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs, int njobs,
+                                                   int W, int H, uint32_t *hist, int chain_len, int chain_stride,
+                                                   void *pieces, uint32_t pieces_cap, uint32_t *npieces,
+                                                   uint8_t *incomplete, void *stream)
+{
+    if (chain_len < 0 || chain_stride < 0 || !pieces || !npieces || !incomplete || !pick_ndw(W) || !k2_options().bound)
+        return set_err(ABUB_E_INVALID, "abub_diff_hist_chained_deferred_dev: bad arguments (or no bound-and-verify pass for this width)");
+    CompactArgs ca = {nullptr, nullptr, 0, nullptr, 0};
+    ca.chain_len = chain_len;
+    ca.chain_stride = chain_stride;
+    ca.df_pieces = (uint2 *)pieces;
+    ca.df_cap = pieces_cap;
+    ca.df_count = npieces;
+    ca.df_incomplete = incomplete;
+    return diff_hist_impl(frames, sigma6, jobs, njobs, W, H, hist, nullptr, 0, ca, stream);
+}
+
+template <int NDW>
+static void launch_pieces(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs, int W, int H, int R, int nchunks,
+                          uint32_t *hist, const uint2 *pieces, const uint32_t *npieces, const uint8_t *want, unsigned grid,
+                          hipStream_t st)
+{
+    hipLaunchKernelGGL((k2_rows<NDW, false, 1, false>), dim3(grid), dim3(64), 0, st, frames, sigma6, jobs, W, H, R, nchunks, hist,
+                       (uint8_t *)nullptr, (const int32_t *)nullptr, (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0u, pieces,
+                       npieces, want);
+}
+
+extern "C" int abub_diff_hist_pieces_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs, int njobs, int W,
+                                         int H, uint32_t *hist, const void *pieces_, const uint32_t *npieces,
+                                         const uint8_t *want, void *stream)
+{
+    const uint2 *pieces = (const uint2 *)pieces_;
+    if (!frames || !sigma6 || !jobs || !hist || !pieces || !npieces || !want || njobs <= 0 || W <= 0 || H <= 0)
+        return set_err(ABUB_E_INVALID, "abub_diff_hist_pieces_dev: bad arguments");
+    const int ndw = pick_ndw(W);
+    if (!ndw)
+        return set_err(ABUB_E_INVALID, "abub_diff_hist_pieces_dev: no fast path for this width");
+    hipStream_t st = (hipStream_t)stream;
+    const int R = k2_auto_rows(njobs, H), nchunks = (H + R - 1) / R; // the geometry of the deferred launch over these njobs jobs
+    const size_t cap = abub_k2_pieces_cap(njobs, W, H);
+    const unsigned grid = (unsigned)(cap < 4096 ? cap : 4096);
+    switch (ndw) {
+    case 1: launch_pieces<1>(frames, sigma6, jobs, W, H, R, nchunks, hist, pieces, npieces, want, grid, st); break;
+    case 2: launch_pieces<2>(frames, sigma6, jobs, W, H, R, nchunks, hist, pieces, npieces, want, grid, st); break;
+    case 3: launch_pieces<3>(frames, sigma6, jobs, W, H, R, nchunks, hist, pieces, npieces, want, grid, st); break;
+    case 4: launch_pieces<4>(frames, sigma6, jobs, W, H, R, nchunks, hist, pieces, npieces, want, grid, st); break;
+    case 5: launch_pieces<5>(frames, sigma6, jobs, W, H, R, nchunks, hist, pieces, npieces, want, grid, st); break;
+    case 6: launch_pieces<6>(frames, sigma6, jobs, W, H, R, nchunks, hist, pieces, npieces, want, grid, st); break;
+    case 7: launch_pieces<7>(frames, sigma6, jobs, W, H, R, nchunks, hist, pieces, npieces, want, grid, st); break;
+    default: launch_pieces<8>(frames, sigma6, jobs, W, H, R, nchunks, hist, pieces, npieces, want, grid, st); break;
+    }
+    HIPCHK(hipGetLastError());
+    // bin 0 of the jobs whose rows are complete now (the deferred launch computed it from partial counts)
+    hipLaunchKernelGGL(k_hist_bin0, dim3(njobs), dim3(64), 0, st, hist, (uint32_t)((size_t)W * H), want);
+    HIPCHK(hipGetLastError());
+    return ABUB_OK;
 }
 
 extern "C" int abub_fast_path(int W) { return pick_ndw(W) != 0; }

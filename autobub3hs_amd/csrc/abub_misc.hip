@@ -145,6 +145,26 @@ void *abub_k2_scratch(hipStream_t st, size_t bytes, std::unique_lock<std::mutex>
     return b.p;
 }
 
+extern "C" int abub_bound_counts_dev(void *stream, uint32_t counts[2])
+{
+    if (!counts)
+        return set_err(ABUB_E_INVALID, "abub_bound_counts_dev: null pointer");
+    counts[0] = counts[1] = 0;
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(g_scratchMu);
+    auto it = g_scratch.find(std::make_pair(dev, st));
+    if (it == g_scratch.end() || !it->second.p)
+        return ABUB_OK;
+    uint32_t c[64];
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpy(c, it->second.p, sizeof c, hipMemcpyDeviceToHost));
+    counts[0] = c[0];  // handed-over pieces
+    counts[1] = c[32]; // entries of the global suspect list
+    return ABUB_OK;
+}
+
 extern "C" int abub_scratch_release(void *stream)
 {
     int dev = 0;

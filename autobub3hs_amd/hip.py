@@ -68,9 +68,49 @@ def diff_hist(frames, sigma6_, jobs, W, H, store=False, rows_per_chunk=0, hist=N
     return hist, (diff if store else None)
 
 
+def diff_hist_deferred(frames, sigma6_, jobs, W, H, chain):
+    """Trigger-only chained K2 with the row machine left out (abub_diff_hist_chained_deferred_dev): -> (hist [n,256] i32,
+    state) where state = (pieces, npieces, incomplete u8 [n]); histograms of jobs with incomplete != 0 are not final
+    until diff_hist_pieces() has completed them."""
+    _need_cuda(frames, sigma6_, jobs)
+    n = jobs.shape[0]
+    hist = torch.empty((n, 256), dtype=torch.int32, device=frames.device)
+    cap = int(_lib.lib().abub_k2_pieces_cap(n, W, H))
+    pieces = torch.empty((max(cap, 1), 2), dtype=torch.int32, device=frames.device)
+    npieces = torch.zeros((1,), dtype=torch.int32, device=frames.device)
+    incomplete = torch.empty((n,), dtype=torch.uint8, device=frames.device)
+    _lib.check(_lib.lib().abub_diff_hist_chained_deferred_dev(_ptr(frames), _ptr(sigma6_), _ptr(jobs), n, W, H, _ptr(hist),
+                                                              int(chain[0]), int(chain[1]), _ptr(pieces), cap, _ptr(npieces),
+                                                              _ptr(incomplete), _stream()),
+               "abub_diff_hist_chained_deferred_dev")
+    return hist, (pieces, npieces, incomplete)
+
+
+def diff_hist_pieces(frames, sigma6_, jobs, W, H, hist, state, want):
+    """Completes the jobs with want[job] != 0 (u8 [n]) of a diff_hist_deferred() launch: row machine on their handed-over
+    rows, histograms finalised in place."""
+    _need_cuda(frames, sigma6_, jobs, want)
+    pieces, npieces, _ = state
+    _lib.check(_lib.lib().abub_diff_hist_pieces_dev(_ptr(frames), _ptr(sigma6_), _ptr(jobs), jobs.shape[0], W, H, _ptr(hist),
+                                                    _ptr(pieces), _ptr(npieces), _ptr(want), _stream()),
+               "abub_diff_hist_pieces_dev")
+    return hist
+
+
 def k2_set_option(name, value):
     """Run-time K2 launcher knob ("bound", "chain", "budget", "pf"); results never depend on them."""
     _lib.check(_lib.lib().abub_k2_set_option(name.encode(), int(value)), "abub_k2_set_option")
+
+
+def bound_counts(stream=None):
+    """(row pieces handed over to the row machine, global suspect-list entries) of the last bound-and-verify launch on
+    `stream` (default: torch's current stream).  Waits for the stream."""
+    import ctypes as C
+
+    st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    out = (C.c_uint32 * 2)()
+    _lib.check(_lib.lib().abub_bound_counts_dev(st, out), "abub_bound_counts_dev")
+    return int(out[0]), int(out[1])
 
 
 def diff_roi(slab, cur, ref, sigma6_, W, H, roi):

@@ -343,6 +343,11 @@ class Pipeline:
         except Exception:
             pass
 
+    def set_sigma(self, sigma):
+        """sigma image(s) (not 6 sigma) on the device: needed only by stacks that fall back to the drop-in path."""
+        lib().abh_pipe_set_sigma.argtypes = [C.c_void_p, C.c_void_p]
+        lib().abh_pipe_set_sigma(self._h, sigma.data_ptr() if hasattr(sigma, "data_ptr") else int(sigma))
+
     def run(self, frames, mu, sigma6, stream=0, sigma=None):
         """frames/mu/sigma6 (and optionally sigma, needed only if a stack falls back to the drop-in path for the
         bellows veto): device pointers (ints) or torch tensors."""
@@ -364,10 +369,11 @@ class Pipeline:
             raise RuntimeError("pipeline: " + L.abh_pipe_error().decode())
 
     def timing(self):
-        out = (C.c_double * 9)()
+        out = (C.c_double * 12)()
         rounds = lib().abh_pipe_timing(self._h, out)
         return dict(zip(("stage1_ms", "stage2_ms", "stage3_ms", "stage4_ms", "total_ms", "s3_gpu_ms", "s3_list_ms",
-                         "s3_bucket_ms", "pairs"), list(out)), rounds=rounds)
+                         "s3_bucket_ms", "pairs", "trigger_jobs", "dropin_stacks", "jobs_completed_on_demand"), list(out)),
+                    rounds=rounds)
 
     def result(self, s):
         L = lib()

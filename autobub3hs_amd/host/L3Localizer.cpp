@@ -317,7 +317,10 @@ bool L3Localizer::isInMask(cv::Rect *genesis_coords, bool bellows)
     }
     const cv::Mat &mask = bellows ? bellows_mask : cam_mask;
     if (mask.empty()) {
-        std::cout << "Mask image not loadable for event " << EventID << " camera " << CameraNumber << "; skipping mask check" << std::endl;
+        // (cameras without a bellows mask file -- cam0 / cam2 of 40l-19 -- get this line for every contour upstream; the
+        // batched pipeline runs its analyzers quietly: hundreds of stacks per step would serialise on the stream's lock)
+        if (!abub::g_quietAnalyzers)
+            std::cout << "Mask image not loadable for event " << EventID << " camera " << CameraNumber << "; skipping mask check" << std::endl;
         return !bellows;
     }
     if (xpix < 0 || ypix < 0 || xpix >= mask.cols || ypix >= mask.rows)

@@ -8,11 +8,13 @@
 
 OutputWriter::BubbleData::BubbleData() : StatusCode(0), frame0(0), event(0), dzdt(0), drdt(0) {}
 
+std::string OutputWriter::PartSuffix;
+
 OutputWriter::OutputWriter(std::string OutDir, std::string run_number, int frameOffset, int NumCams)
 {
     this->OutputDir = OutDir;
     this->run_number = run_number;
-    this->abubOutFilename = this->OutputDir + "abub3hs_" + this->run_number + ".txt";
+    this->abubOutFilename = this->OutputDir + "abub3hs_" + this->run_number + PartSuffix + ".txt";
     this->frameOffset = frameOffset;
     this->NumCams = NumCams;
     this->camera = 0;

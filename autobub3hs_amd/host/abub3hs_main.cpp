@@ -9,11 +9,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <iostream>
+#include <sstream>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <sched.h>
 
 #include "AlgorithmTraining/Trainer.hpp"
 #include "BubbleLocalizer/L3Localizer.hpp"
@@ -41,17 +45,78 @@ static std::string usage()
            "  --debug = Int\t\t\t3 digit int; eg: 101: first digit = localizer debug; second digit = multithread off; third digit = analyzer debug\n"
            "MI355X options:\n"
            "  --gpus = Int\t\t\tGPUs to spread the event batches over (one worker thread per GPU; default 1)\n"
-           "  --gpu-shard = r/N\t\tprocess only the events whose index in the sorted event list is r modulo N\n"
+           "  --gpu-shard = r/N\t\tprocess only the events whose index in the sorted event list is r modulo N;\n"
+           "\t\t\t\twrites abub3hs_<run>.part<r>of<N>.txt (N > 1)\n"
+           "  --merge = N\t\t\tassemble abub3hs_<run>.txt in --out_dir from the N part files of a sharded run\n"
            "  --per-event\t\t\tone analyzer at a time like the reference's loop (also chosen by -e and --debug);\n"
            "\t\t\t\tdefault: whole batches of events decoded into pinned memory and analysed together\n";
 }
 
 static bool eventNameOrderSort(const std::string &a, const std::string &b) { return std::stoi(a) < std::stoi(b); }
 
+// cores this process may run on (cgroup / taskset aware), the reference's omp_get_max_threads() (AutoBubStart3.cpp:338)
+static int usableCores()
+{
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0)
+        return CPU_COUNT(&set);
+    return (int)std::max(1u, std::thread::hardware_concurrency());
+}
+
+// --merge N: the reference writes ONE file in event order (the `ordered` clause, AutoBubStart3.cpp:380-383).  Shard r of N
+// holds the events r, r + N, .. of the sorted event list, one block of rows per event, in order: the header comes from
+// part 0, then the blocks are dealt back round-robin.  A block = consecutive rows with the same event number (column 2).
+static int mergeParts(const std::string &out_dir, const std::string &run_number, int N)
+{
+    std::vector<std::vector<std::string>> blocks((size_t)N);
+    std::string header;
+    for (int r = 0; r < N; ++r) {
+        const std::string path = out_dir + "abub3hs_" + run_number + ".part" + std::to_string(r) + "of" + std::to_string(N) + ".txt";
+        std::ifstream in(path);
+        if (!in) {
+            std::cerr << "--merge: cannot read " << path << std::endl;
+            return -1;
+        }
+        std::string line, head, lastEv;
+        for (int k = 0; k < 6 && std::getline(in, line); ++k) // 3 header lines, "8", two blank lines (writeHeader)
+            head += line + "\n";
+        if (r == 0)
+            header = head;
+        else if (head != header) {
+            std::cerr << "--merge: " << path << " has a different header" << std::endl;
+            return -1;
+        }
+        while (std::getline(in, line)) {
+            std::istringstream ls(line);
+            std::string run, ev;
+            ls >> run >> ev;
+            if (blocks[r].empty() || ev != lastEv)
+                blocks[r].push_back(std::string());
+            blocks[r].back() += line + "\n";
+            lastEv = ev;
+        }
+    }
+    std::ofstream out(out_dir + "abub3hs_" + run_number + ".txt");
+    if (!out) {
+        std::cerr << "--merge: cannot write into " << out_dir << std::endl;
+        return -1;
+    }
+    out << header;
+    size_t longest = 0;
+    for (auto &b : blocks)
+        longest = std::max(longest, b.size());
+    for (size_t j = 0; j < longest; ++j)
+        for (int r = 0; r < N; ++r)
+            if (j < blocks[r].size())
+                out << blocks[r][j];
+    return out.good() ? 0 : -1;
+}
+
 int main(int argc, char **argv)
 {
     std::string dataLoc, run_number, out_dir, mask_dir, data_series;
-    int event_user = -1, debug_mode = 0, ngpus = 1, shardRank = 0, shardWorld = 1;
+    int event_user = -1, debug_mode = 0, ngpus = 1, shardRank = 0, shardWorld = 1, mergeN = 0;
     bool zipped = false, mask_check = false, help = argc == 1, perEvent = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i], v;
@@ -94,6 +159,13 @@ int main(int argc, char **argv)
                 std::cerr << "--gpu-shard expects r/N with 0 <= r < N" << std::endl;
                 return -1;
             }
+        } else if (a.rfind("--merge", 0) == 0) {
+            value(v);
+            mergeN = atoi(v.c_str());
+            if (mergeN < 1) {
+                std::cerr << "--merge expects the number of shards" << std::endl;
+                return -1;
+            }
         } else if (a == "--per-event") {
             perEvent = true;
         } else {
@@ -104,6 +176,15 @@ int main(int argc, char **argv)
     if (help) {
         std::cout << usage() << std::endl;
         return 1;
+    }
+    if (mergeN > 0) {
+        if (run_number.empty() || out_dir.empty()) {
+            std::cerr << "--merge needs --run_id and --out_dir" << std::endl;
+            return -1;
+        }
+        if (out_dir[out_dir.length() - 1] != '/')
+            out_dir += "/";
+        return mergeParts(out_dir, run_number, mergeN);
     }
     if (dataLoc.empty() || run_number.empty() || out_dir.empty()) {
         std::cerr << "Insufficient required arguments; use \"autobub3hs -h\" to view required arguments" << std::endl;
@@ -146,11 +227,17 @@ int main(int argc, char **argv)
     if (const char *nc = getenv("ABUB_NUM_CAMS")) // synthetic runs with fewer cameras
         numCams = atoi(nc);
 
-    int nthreads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    // Threads.  The reference runs omp_get_max_threads() events at once (AutoBubStart3.cpp:338-342): the per-event loop and
+    // the decoders of the batched path take every core this process may use (at most 128); the host stages of the batched
+    // pipeline (state machines, contours) saturate at about 16.  ABUB_THREADS / ABUB_DECODE_THREADS override.
+    const int cores = usableCores();
+    int nthreads = std::min(cores, 128), hostThreads = std::min(cores, 16), decodeThreads = std::min(cores, 128);
     if (const char *t = getenv("ABUB_THREADS"))
-        nthreads = std::max(1, atoi(t));
+        nthreads = hostThreads = decodeThreads = std::max(1, atoi(t));
     if (debug_mode % 100 / 10)
-        nthreads = 1;
+        nthreads = hostThreads = decodeThreads = 1;
+    if (shardWorld > 1) // every shard writes its own part file (--merge N assembles the run's file)
+        OutputWriter::PartSuffix = ".part" + std::to_string(shardRank) + "of" + std::to_string(shardWorld);
 
     OutputWriter *header = new OutputWriter(out_dir, run_number, frameOffset, numCams);
     header->writeHeader();
@@ -165,9 +252,11 @@ int main(int argc, char **argv)
         FileParser->GetEventDirLists(EventList);
     } catch (...) {
         std::cout << "Failed to read the images from run " << run_number << ". Autobub cannot continue.\n";
-        for (int icam = 0; icam < numCams; icam++)
-            header->stageCameraOutputError(icam, -5, -1);
-        header->writeCameraOutput();
+        if (shardRank == 0) { // (one block for the run: it goes into part 0 of a sharded run)
+            for (int icam = 0; icam < numCams; icam++)
+                header->stageCameraOutputError(icam, -5, -1);
+            header->writeCameraOutput();
+        }
         return -5;
     }
     std::sort(EventList.begin(), EventList.end(), eventNameOrderSort);
@@ -197,6 +286,8 @@ int main(int argc, char **argv)
     if (!succeeded) {
         std::cout << "Failed to train on images from run " << run_number << ". Autobub cannot continue.\n";
         for (size_t evi = 0; evi < EventList.size(); evi++) {
+            if (shardWorld > 1 && (int)(evi % (size_t)shardWorld) != shardRank)
+                continue;
             for (int icam = 0; icam < numCams; icam++)
                 header->stageCameraOutputError(icam, -7, atoi(EventList[evi].c_str()));
             header->writeCameraOutput();
@@ -216,8 +307,8 @@ int main(int argc, char **argv)
         bo.ngpus = ngpus;
         if (const char *d = getenv("ABUB_DEVICE"))
             bo.firstDevice = atoi(d);
-        bo.hostThreads = nthreads;
-        bo.decodeThreads = nthreads;
+        bo.hostThreads = hostThreads;
+        bo.decodeThreads = decodeThreads;
         if (const char *t = getenv("ABUB_DECODE_THREADS"))
             bo.decodeThreads = std::max(1, atoi(t));
         if (const char *b = getenv("ABUB_BATCH_MB"))

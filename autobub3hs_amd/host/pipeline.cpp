@@ -61,10 +61,28 @@ struct PlannedImage {
     uint32_t nfg = 0;
 };
 
+// thrown by the batched provider when the trigger search asks for a frame whose block has not been evaluated yet: the
+// pipeline evaluates that block for the stack and runs the search again (see RunPipeline::runGroup)
+struct NeedMoreFrames : public std::runtime_error {
+    NeedMoreFrames() : std::runtime_error("trigger search needs the next block of frames") {}
+};
+
 // EventData served from the pipeline's batched results
 class BatchEventData : public EventData {
 public:
-    const uint32_t *hists = nullptr; // [F-1][256] of this stack (frame i at (i-1)*256)
+    // The trigger search's histograms arrive in blocks of frames: block k covers frames [bstart[k], bstart[k + 1]) and
+    // bh[k] points at its histograms once that block has been evaluated for this stack (frame i at (i - bstart[k]) * 256).
+    static constexpr int MAXB = 32;
+    int nblocks = 0;
+    int bstart[MAXB + 1] = {0};
+    const uint32_t *bh[MAXB] = {nullptr};
+    // inc[k] (optional): per frame of block k, 1 while the frame's histogram is not final -- its dense rows were handed over
+    // by the bound scan and the row machine has not run on them yet (deferred pieces); cleared when they are completed
+    uint8_t *inc[MAXB] = {nullptr};
+    int fetchOf[MAXB] = {0}, slotOf[MAXB] = {0}; // which launch of block k served this stack, and its position in it
+    int needBlock = -1;    // set when diffHist() throws NeedMoreFrames ...
+    bool needPieces = false; // ... true: block needBlock is there, but frame needFrame (and later ones) must be completed
+    int needFrame = 0;
     int refOffset = 2;
     const uint32_t *roundHists = nullptr; // [nslots][256] of the current round
     std::vector<PlannedImage> planned;
@@ -77,7 +95,21 @@ public:
     {
         if (off != refOffset || i < 1 || i >= F)
             throw std::runtime_error("BatchEventData::diffHist: unplanned request");
-        return hists + (size_t)(i - 1) * 256;
+        int k = 0;
+        while (k + 1 < nblocks && i >= bstart[k + 1])
+            ++k;
+        if (!bh[k]) {
+            needBlock = k;
+            needPieces = false;
+            throw NeedMoreFrames();
+        }
+        if (inc[k] && inc[k][i - bstart[k]]) {
+            needBlock = k;
+            needPieces = true;
+            needFrame = i;
+            throw NeedMoreFrames();
+        }
+        return bh[k] + (size_t)(i - bstart[k]) * 256;
     }
     const uint32_t *find(int kind, int i, int ref)
     {
@@ -127,6 +159,7 @@ struct StackState {
     bool done = false;
     bool localize = false;
     bool dropIn = false; // must be re-run through the one-at-a-time path (bellows veto)
+    bool needMore = false; // the trigger search stopped at a frame block that is not evaluated yet (data.needBlock)
     std::string error;
     std::vector<BubbleOut> bubbles;
     int trig = 0, status = 0, loc_thres = 3, ok = 1;
@@ -258,15 +291,30 @@ struct Group {
     int s0 = 0, s1 = 0; // stacks [s0, s1)
     hipStream_t stream = nullptr;
     hipEvent_t stage1Done = nullptr, kernelsDone = nullptr;
-    abub_job *d_jobs1 = nullptr;
-    uint32_t *d_hist1 = nullptr;
+    // trigger search, per frame block: job lists and histograms (capacity: every stack of the group once)
+    std::vector<abub_job *> d_jobsB, h_jobsB;
+    std::vector<uint32_t *> d_histB, h_histB;
+    std::vector<int> usedB; // stacks already served per block in this run (each stack fetches a block at most once)
+    // deferred pieces, per block: handed-over row ranges of every launch of the block, per-launch counters, per-job
+    // "incomplete" / "wanted" flags
+    struct Fetch {
+        int first = 0, n = 0;   // stacks [first, first + n) of the block's buffers
+        size_t pieceOff = 0;    // its range of the block's piece list
+        bool deferred = false;
+    };
+    std::vector<std::vector<Fetch>> fetches;
+    std::vector<void *> d_piecesB;
+    std::vector<uint32_t *> d_pcountB;
+    std::vector<uint8_t *> d_incB, h_incB, d_wantB, h_wantB;
+    std::vector<size_t> pieceCapB, pieceUsedB;
+    hipEvent_t blockDone = nullptr;
     abub_job *d_jobs3 = nullptr;
     uint32_t *d_hist3 = nullptr;
     uint8_t *d_img = nullptr;
     int32_t *d_thr = nullptr;
     uint32_t *d_pairs = nullptr, *d_count = nullptr, *d_gscratch = nullptr, *d_goff = nullptr, *d_gidx = nullptr;
     uint8_t *d_gval = nullptr;
-    uint32_t *h_hist1 = nullptr, *h_hist3 = nullptr, *h_count = nullptr, *h_goff = nullptr, *h_gidx = nullptr;
+    uint32_t *h_hist3 = nullptr, *h_count = nullptr, *h_goff = nullptr, *h_gidx = nullptr;
     uint8_t *h_gval = nullptr;
     abub_job *h_jobs3 = nullptr;
     int32_t *h_thr = nullptr;
@@ -286,11 +334,16 @@ public:
     std::string maskDir;
     std::vector<Group> groups;
     std::unique_ptr<WorkerPool> pool;
+    std::vector<int> blocks;            // frame blocks of the trigger search: block k = frames [blocks[k], blocks[k + 1])
+    bool deferPieces = false;           // trigger search: dense frames' rows are evaluated on demand (see the constructor)
+    long long jobsCompleted = 0;        // ... jobs of the last run that were completed that way
+    long long jobsLaunched = 0;         // trigger-search jobs of the last run (F - 1 per stack when nothing is lazy)
+    int dropIns = 0;                    // stacks of the last run that went through the one-at-a-time path (bellows veto)
     hipStream_t stage1Stream = nullptr; // all trigger-search launches, in group order (see run())
     int chainStride = 0;                // FindTriggerFrame's frame offset when every camera shares it, else 0
     bool ordered = true;                // localisation kernels queue on stage1Stream too (see batchImages())
     std::vector<void *> devAllocs, hostAllocs;
-    std::mutex allocMu;
+    std::mutex allocMu, launchMu;
     std::vector<StackState> stacks;
     std::vector<Trainer *> trainers;
     MemParser parser;
@@ -308,6 +361,78 @@ public:
                 throw std::runtime_error("RunPipeline::setStackMeta: stack longer than the pipeline's frame count");
             metaParser.AddNamedFrames(meta[s].eventID, s % C, meta[s].names);
         }
+    }
+    // trigger-search job of frame i of stack s (FindTriggerFrame's pairing: ref = max(i - off, 0), off = 1 when the model
+    // was trained on fewer than 6 frames, AnalyzerUnit.cpp:185-188).  Frames a shorter stack does not have are replaced
+    // by its last one on both sides (D = 0: a quiet job that keeps the chain structure the scan relies on).
+    abub_job triggerJob(int s, int i, uint32_t out) const
+    {
+        const int c = s % C, off = tss[c] < 6 ? 1 : 2;
+        const int Fs = meta.empty() ? F : (int)meta[s].names.size();
+        const int last = std::max(Fs - 1, 0);
+        abub_job j;
+        j.cur = (uint32_t)(s * F + std::min(i, last));
+        j.ref = (uint32_t)(s * F + std::min(std::max(i - off, 0), last));
+        j.model = (uint32_t)c;
+        j.out = out;
+        return j;
+    }
+    // after the launch of block k has been waited for: the stack at position q of fetch `f` gets its histograms (and flags)
+    void bindBlock(Group &G, StackState &st_, int k, int f, int q)
+    {
+        const Group::Fetch &fe = G.fetches[k][f];
+        const size_t blen = (size_t)(blocks[k + 1] - blocks[k]), slot = (size_t)fe.first + q;
+        st_.data.bh[k] = G.h_histB[k] + slot * blen * 256;
+        st_.data.inc[k] = fe.deferred ? G.h_incB[k] + slot * blen : nullptr;
+        st_.data.fetchOf[k] = f;
+        st_.data.slotOf[k] = q;
+    }
+    // K2 over block k for the listed stacks (all of them on the same block): jobs -> device, launch, histograms -> host.
+    // Returns the first slot (in stacks) of the block's histogram buffer the results go to.
+    int launchBlock(Group &G, int k, const std::vector<int> &list, const uint8_t *d_frames, const uint8_t *d_sigma6,
+                    hipStream_t stream)
+    {
+        const int a = blocks[k], blen = blocks[k + 1] - blocks[k];
+        const int first = G.usedB[k], n = (int)list.size();
+        if (blen <= 0 || n == 0)
+            return first;
+        if (first + n > G.s1 - G.s0)
+            throw std::runtime_error("RunPipeline: a frame block was requested twice for one stack");
+        abub_job *hj = G.h_jobsB[k] + (size_t)first * blen;
+        for (int q = 0; q < n; ++q)
+            for (int i = 0; i < blen; ++i)
+                hj[(size_t)q * blen + i] = triggerJob(list[q], a + i, (uint32_t)((size_t)q * blen + i));
+        abub_job *dj = G.d_jobsB[k] + (size_t)first * blen;
+        uint32_t *dh = G.d_histB[k] + (size_t)first * blen * 256, *hh = G.h_histB[k] + (size_t)first * blen * 256;
+        const int nj = n * blen;
+        HIPOK(hipMemcpyAsync(dj, hj, (size_t)nj * sizeof(abub_job), hipMemcpyHostToDevice, stream));
+        Group::Fetch fe;
+        fe.first = first;
+        fe.n = n;
+        const size_t pcap = deferPieces ? abub_k2_pieces_cap(nj, W, H) : 0;
+        if (deferPieces && G.fetches[k].size() < 64 && G.pieceUsedB[k] + pcap <= G.pieceCapB[k]) {
+            // the scan alone: dense frames' rows go to this launch's range of the block's piece list, their jobs are flagged
+            fe.deferred = true;
+            fe.pieceOff = G.pieceUsedB[k];
+            G.pieceUsedB[k] += pcap;
+            uint8_t *dinc = G.d_incB[k] + (size_t)first * blen, *hinc = G.h_incB[k] + (size_t)first * blen;
+            check(abub_diff_hist_chained_deferred_dev(d_frames, d_sigma6, dj, nj, W, H, dh, blen, chainStride,
+                                                      (uint64_t *)G.d_piecesB[k] + fe.pieceOff, (uint32_t)pcap,
+                                                      G.d_pcountB[k] + G.fetches[k].size(), dinc, stream),
+                  "trigger search K2 (deferred pieces)");
+            HIPOK(hipMemcpyAsync(hinc, dinc, (size_t)nj, hipMemcpyDeviceToHost, stream));
+        } else {
+            // all cameras on the same frame offset: per stack the jobs are a chain (job i refs the cur frame of job i - off)
+            // and the scan loads every frame row once for both of its jobs
+            check(chainStride > 0 ? abub_diff_hist_chained_dev(d_frames, d_sigma6, dj, nj, W, H, dh, blen, chainStride, stream)
+                                  : abub_diff_hist_dev(d_frames, d_sigma6, dj, nj, W, H, dh, nullptr, 0, stream),
+                  "trigger search K2");
+        }
+        HIPOK(hipMemcpyAsync(hh, dh, (size_t)nj * 1024, hipMemcpyDeviceToHost, stream));
+        G.fetches[k].push_back(fe);
+        G.usedB[k] = first + n;
+        jobsLaunched += nj;
+        return first;
     }
     double tms[8] = {0};
     int rounds = 0;
@@ -357,13 +482,35 @@ public:
                 chainStride = 0;
         groups.resize(ngroups);
         pool.reset(new WorkerPool(std::max(0, nthreads - ngroups))); // the group driver threads take part too
-        // stage-1 jobs: FindTriggerFrame's pairing, ref = max(i - off, 0) with off = 1 when the model was
-        // trained on fewer than 6 frames (AnalyzerUnit.cpp:185-188); `out` is relative to the group's slab
+        // Frame blocks of the trigger search.  The reference walks the frames in order and stops at the trigger
+        // (AnalyzerUnit.cpp:191, break at :307); it never differences the frames behind it unless the localizer finds no
+        // bubble and the search goes on (AutoBubStart3.cpp:87-110).  So the histograms are produced block by block: block 0
+        // for every stack up front, later blocks only for the stacks whose search reaches them.  ABUB_PIPE_LAZY=0: one
+        // block (every frame of every stack up front, what round 2 did).
+        {
+            const char *el = getenv("ABUB_PIPE_LAZY");
+            const bool lazy = el ? atoi(el) != 0 : true;
+            const char *e0 = getenv("ABUB_PIPE_BLOCK0"), *e1 = getenv("ABUB_PIPE_BLOCK");
+            // first block: up to the frame the cameras' own trigger puts the bubble at (the middle of the stack) plus the
+            // two look-ahead frames and a margin; then blocks of about a fifth of the stack
+            int first = e0 && atoi(e0) > 0 ? atoi(e0) : F / 2 + 4, step = e1 && atoi(e1) > 0 ? atoi(e1) : std::max(4, F / 5);
+            blocks.clear();
+            blocks.push_back(1);
+            if (lazy && F > 8)
+                for (int b = std::min(first + 1, F); b < F && (int)blocks.size() < BatchEventData::MAXB; b += step)
+                    blocks.push_back(b);
+            blocks.push_back(std::max(F, 1)); // block k = frames [blocks[k], blocks[k + 1])
+            // Deferred pieces: inside a block the bound scan still covers every frame, but the row machine runs only on the
+            // dense frames a search actually reaches (ABUB_PIPE_DEFER=0: at once, for every frame of the block).
+            const char *ed = getenv("ABUB_PIPE_DEFER");
+            deferPieces = (ed ? atoi(ed) != 0 : true) && chainStride > 0 && abub_fast_path(W) != 0;
+        }
+        const int nB = (int)blocks.size() - 1;
         for (int g = 0; g < ngroups; ++g) {
             Group &G = groups[g];
             G.s0 = (int)((long long)S * g / ngroups);
             G.s1 = (int)((long long)S * (g + 1) / ngroups);
-            const size_t ns = (size_t)(G.s1 - G.s0), n1 = ns * std::max(F - 1, 1), n3 = ns * K;
+            const size_t ns = (size_t)(G.s1 - G.s0), n3 = ns * K;
             G.nthreads = std::max(1, nthreads / ngroups);
             const char *ec = getenv("ABUB_PIPE_PAIRCAP"); // initial candidate-list capacity (grows on demand)
             G.pairCap = ec && atoi(ec) > 0 ? (uint32_t)atoi(ec) : (8u << 20) / ngroups;
@@ -372,8 +519,26 @@ public:
             HIPOK(hipStreamCreateWithPriority(&G.stream, hipStreamNonBlocking, prHigh));
             HIPOK(hipEventCreateWithFlags(&G.stage1Done, hipEventDisableTiming));
             HIPOK(hipEventCreateWithFlags(&G.kernelsDone, hipEventDisableTiming));
-            G.d_jobs1 = dalloc<abub_job>(n1);
-            G.d_hist1 = dalloc<uint32_t>(n1 * 256);
+            HIPOK(hipEventCreateWithFlags(&G.blockDone, hipEventDisableTiming));
+            G.usedB.assign(nB, 0);
+            for (int k = 0; k < nB; ++k) {
+                const size_t nj = ns * (size_t)std::max(blocks[k + 1] - blocks[k], 1);
+                G.d_jobsB.push_back(dalloc<abub_job>(nj));
+                G.h_jobsB.push_back(halloc<abub_job>(nj));
+                G.d_histB.push_back(dalloc<uint32_t>(nj * 256));
+                G.h_histB.push_back(halloc<uint32_t>(nj * 256));
+                // deferred pieces: at most H / 16 + 8 row ranges per job (chunks are at least 16 rows), 64 launches per block
+                const size_t pc = deferPieces ? nj * (size_t)(H / 16 + 8) : 1;
+                G.pieceCapB.push_back(pc);
+                G.d_piecesB.push_back((void *)dalloc<uint64_t>(pc));
+                G.d_pcountB.push_back(dalloc<uint32_t>(64));
+                G.d_incB.push_back(dalloc<uint8_t>(nj));
+                G.h_incB.push_back(halloc<uint8_t>(nj));
+                G.d_wantB.push_back(dalloc<uint8_t>(nj));
+                G.h_wantB.push_back(halloc<uint8_t>(nj));
+            }
+            G.fetches.assign(nB, std::vector<Group::Fetch>());
+            G.pieceUsedB.assign(nB, 0);
             G.d_jobs3 = dalloc<abub_job>(n3);
             G.d_hist3 = dalloc<uint32_t>(n3 * 256);
             G.d_img = dalloc<uint8_t>(abub_fast_path(W) ? 256 : n3 * P); // only the unfused fallback stores images
@@ -384,7 +549,6 @@ public:
             G.d_goff = dalloc<uint32_t>(n3 + 1);
             G.d_gidx = dalloc<uint32_t>(G.pairCap);
             G.d_gval = dalloc<uint8_t>(G.pairCap);
-            G.h_hist1 = halloc<uint32_t>(n1 * 256);
             G.h_hist3 = halloc<uint32_t>(n3 * 256);
             G.h_count = halloc<uint32_t>(1);
             G.h_goff = halloc<uint32_t>(n3 + 1);
@@ -392,19 +556,6 @@ public:
             G.h_gval = halloc<uint8_t>(G.pairCap);
             G.h_jobs3 = halloc<abub_job>(n3);
             G.h_thr = halloc<int32_t>(n3);
-            std::vector<abub_job> j1(n1);
-            for (int s = G.s0; s < G.s1; ++s) {
-                const int c = s % C, off = tss[c] < 6 ? 1 : 2;
-                for (int i = 1; i < F; ++i) {
-                    abub_job &j = j1[(size_t)(s - G.s0) * (F - 1) + (i - 1)];
-                    j.cur = (uint32_t)(s * F + i);
-                    j.ref = (uint32_t)(s * F + std::max(i - off, 0));
-                    j.model = (uint32_t)c;
-                    j.out = (uint32_t)((size_t)(s - G.s0) * (F - 1) + (i - 1));
-                }
-            }
-            if (F > 1)
-                HIPOK(hipMemcpy(G.d_jobs1, j1.data(), n1 * sizeof(abub_job), hipMemcpyHostToDevice));
         }
         // frame names only: the images live in HBM
         for (int c = 0; c < C; ++c) {
@@ -431,6 +582,8 @@ public:
                 (void)hipEventDestroy(G.stage1Done);
             if (G.kernelsDone)
                 (void)hipEventDestroy(G.kernelsDone);
+            if (G.blockDone)
+                (void)hipEventDestroy(G.blockDone);
         }
         if (stage1Stream) {
             (void)abub_scratch_release(stage1Stream); // the trigger search's work list lives in library scratch
@@ -492,21 +645,20 @@ public:
         // Stage 1 of every group goes to ONE stream in group order: the trigger search of group g+1 runs
         // on the GPU while the host threads of group g are in their state machines (two kernels launched on
         // different streams would simply share the chip and finish together, leaving nothing to overlap).
+        jobsLaunched = jobsCompleted = 0;
         for (size_t gi = 0; gi < groups.size(); ++gi) {
             Group &G = groups[gi];
             if (waitCopies)
                 HIPOK(hipStreamWaitEvent(stage1Stream, copied[gi], 0));
-            const int n1 = (G.s1 - G.s0) * (F - 1);
-            if (n1 > 0) {
-                // all cameras on the same frame offset: the job list is F-1 long chains per stack (job i refs the
-                // cur frame of job i - off) and the scan loads every frame row once for both of its jobs
-                check(chainStride > 0
-                          ? abub_diff_hist_chained_dev(d_frames, d_sigma6, G.d_jobs1, n1, W, H, G.d_hist1, F - 1, chainStride,
-                                                       stage1Stream)
-                          : abub_diff_hist_dev(d_frames, d_sigma6, G.d_jobs1, n1, W, H, G.d_hist1, nullptr, 0, stage1Stream),
-                      "stage1 K2");
-                HIPOK(hipMemcpyAsync(G.h_hist1, G.d_hist1, (size_t)n1 * 1024, hipMemcpyDeviceToHost, stage1Stream));
-            }
+            std::fill(G.usedB.begin(), G.usedB.end(), 0);
+            std::fill(G.pieceUsedB.begin(), G.pieceUsedB.end(), 0);
+            for (auto &fv : G.fetches)
+                fv.clear();
+            std::vector<int> all;
+            for (int sI = G.s0; sI < G.s1; ++sI)
+                all.push_back(sI);
+            if (F > 1)
+                launchBlock(G, 0, all, d_frames, d_sigma6, stage1Stream); // block 0: every stack, slot == index in the group
             HIPOK(hipEventRecord(G.stage1Done, stage1Stream));
         }
         std::vector<std::thread> th;
@@ -519,9 +671,12 @@ public:
         rounds = 0;
         lastPairs = 0;
         // stacks the batched providers could not serve (bellows veto): one at a time through the drop-in path
+        dropIns = 0;
         for (int s = 0; s < S; ++s)
-            if (stacks[s].dropIn)
+            if (stacks[s].dropIn) {
+                ++dropIns;
                 runDropIn(s, d_frames, d_mu);
+            }
         for (Group &G : groups) {
             if (!G.error.empty())
                 throw std::runtime_error(G.error);
@@ -641,7 +796,16 @@ private:
             st_.data.W = W;
             st_.data.H = H;
             st_.data.refOffset = tss[c] < 6 ? 1 : 2;
-            st_.data.hists = G.h_hist1 + (size_t)k * (F - 1) * 256;
+            st_.data.nblocks = (int)blocks.size() - 1;
+            for (size_t b = 0; b < blocks.size(); ++b)
+                st_.data.bstart[b] = blocks[b];
+            for (int b = 0; b < st_.data.nblocks; ++b) {
+                st_.data.bh[b] = nullptr;
+                st_.data.inc[b] = nullptr;
+            }
+            // block 0 was launched for every stack of the group, in group order (fetch 0, position k)
+            if (F > 1)
+                bindBlock(G, st_, 0, 0, k);
             st_.analyzer->AttachEventData(&st_.data);
         });
         HIPOK(hipEventSynchronize(G.stage1Done));
@@ -653,8 +817,21 @@ private:
         while (!pending.empty()) {
             ++G.rounds;
             // ---- stage 2: trigger search + plan ------------------------------------------------
+            // A search that runs into a frame block which has not been evaluated for its stack stops there
+            // (NeedMoreFrames); those blocks are evaluated -- one launch per block index -- and the searches run again.
             double t2 = nowMs();
-            pool->parallelFor((int)pending.size(), [&](int k) { triggerAndPlan(stacks[pending[k]]); });
+            std::vector<int> todo(pending);
+            while (!todo.empty()) {
+                pool->parallelFor((int)todo.size(), [&](int k) { triggerAndPlan(stacks[todo[k]]); });
+                std::vector<int> need;
+                for (int sI : todo)
+                    if (stacks[sI].needMore)
+                        need.push_back(sI);
+                if (need.empty())
+                    break;
+                fetchBlocks(G, need, d_frames, d_sigma6);
+                todo.swap(need);
+            }
             G.tms[1] += nowMs() - t2;
             // ---- stage 3: batched images, thresholds, foreground ---------------------------------
             double t3 = nowMs();
@@ -695,13 +872,108 @@ private:
         });
     }
 
+    // What the stopped searches asked for: the next frame block of a stack (one launch per block index), or the dense rows
+    // of frames of a block that is already there (one row-machine launch per launch of the block that holds them).
+    void fetchBlocks(Group &G, const std::vector<int> &need, const uint8_t *d_frames, const uint8_t *d_sigma6)
+    {
+        hipStream_t stream = ordered ? stage1Stream : G.stream;
+        const int nB = (int)blocks.size() - 1;
+        std::vector<std::vector<int>> byBlock((size_t)nB);
+        std::vector<std::vector<std::vector<int>>> byFetch((size_t)nB); // [block][fetch] -> stacks that need pieces
+        for (int sI : need) {
+            const BatchEventData &d = stacks[sI].data;
+            if (!d.needPieces)
+                byBlock[(size_t)d.needBlock].push_back(sI);
+            else {
+                auto &v = byFetch[(size_t)d.needBlock];
+                if (v.size() <= (size_t)d.fetchOf[d.needBlock])
+                    v.resize((size_t)d.fetchOf[d.needBlock] + 1);
+                v[(size_t)d.fetchOf[d.needBlock]].push_back(sI);
+            }
+        }
+        std::vector<int> newFetch((size_t)nB, -1);
+        {
+            std::lock_guard<std::mutex> lock(launchMu); // (the counters, and one launch sequence at a time per pipeline)
+            for (int k = 0; k < nB; ++k) {
+                if (!byBlock[k].empty()) {
+                    launchBlock(G, k, byBlock[k], d_frames, d_sigma6, stream);
+                    newFetch[k] = (int)G.fetches[k].size() - 1;
+                }
+                const size_t blen = (size_t)(blocks[k + 1] - blocks[k]);
+                for (size_t f = 0; f < byFetch[k].size(); ++f) {
+                    if (byFetch[k][f].empty())
+                        continue;
+                    // complete, for every asking stack, the flagged frames from the one it stopped at to the end of the block
+                    const Group::Fetch &fe = G.fetches[k][f];
+                    const size_t nj = (size_t)fe.n * blen, base = (size_t)fe.first * blen;
+                    uint8_t *hw = G.h_wantB[k] + base;
+                    std::memset(hw, 0, nj);
+                    for (int sI : byFetch[k][f]) {
+                        BatchEventData &d = stacks[sI].data;
+                        for (size_t j = (size_t)(d.needFrame - blocks[k]); j < blen; ++j)
+                            if (d.inc[k][j]) {
+                                hw[(size_t)d.slotOf[k] * blen + j] = 1;
+                                ++jobsCompleted;
+                            }
+                    }
+                    HIPOK(hipMemcpyAsync(G.d_wantB[k] + base, hw, nj, hipMemcpyHostToDevice, stream));
+                    check(abub_diff_hist_pieces_dev(d_frames, d_sigma6, G.d_jobsB[k] + base, (int)nj, W, H, G.d_histB[k] + base * 256,
+                                                    (uint64_t *)G.d_piecesB[k] + fe.pieceOff, G.d_pcountB[k] + f, G.d_wantB[k] + base,
+                                                    stream),
+                          "trigger search K2 (pieces)");
+                    for (int sI : byFetch[k][f]) {
+                        BatchEventData &d = stacks[sI].data;
+                        const size_t j0 = (size_t)(d.needFrame - blocks[k]), o = (base + (size_t)d.slotOf[k] * blen + j0) * 256;
+                        HIPOK(hipMemcpyAsync(G.h_histB[k] + o, G.d_histB[k] + o, (blen - j0) * 1024, hipMemcpyDeviceToHost, stream));
+                    }
+                }
+            }
+            HIPOK(hipEventRecord(G.blockDone, stream));
+        }
+        HIPOK(hipEventSynchronize(G.blockDone));
+        for (int k = 0; k < nB; ++k) {
+            for (size_t q = 0; q < byBlock[k].size(); ++q) {
+                StackState &st_ = stacks[byBlock[k][q]];
+                bindBlock(G, st_, k, newFetch[k], (int)q);
+                st_.needMore = false;
+            }
+            const size_t blen = (size_t)(blocks[k + 1] - blocks[k]);
+            for (auto &v : byFetch[k])
+                for (int sI : v) {
+                    StackState &st_ = stacks[sI];
+                    for (size_t j = (size_t)(st_.data.needFrame - blocks[k]); j < blen; ++j)
+                        st_.data.inc[k][j] = 0; // final now
+                    st_.needMore = false;
+                }
+        }
+    }
+
     // AnyCamAnalysis body up to LocalizeOMatic (AutoBubStart3.cpp:87-107)
     void triggerAndPlan(StackState &st_)
     {
         st_.localize = false;
+        st_.needMore = false;
         AnalyzerUnit *A = st_.analyzer.get();
         try {
-            A->FindTriggerFrame(true, A->MatTrigFrame + 1);
+            // what the search may change before it runs out of evaluated frames (it only ever appends to pix_counts)
+            size_t pixSize[256];
+            const bool havePix = A->pix_counts.size() == 256;
+            for (int b = 0; havePix && b < 256; ++b)
+                pixSize[b] = A->pix_counts[b].size();
+            const int trig0 = A->MatTrigFrame, loc0 = A->loc_thres, status0 = A->TriggerFrameIdentificationStatus;
+            const bool ok0 = A->okToProceed;
+            try {
+                A->FindTriggerFrame(true, A->MatTrigFrame + 1);
+            } catch (NeedMoreFrames &) {
+                for (int b = 0; havePix && b < 256 && A->pix_counts.size() == 256; ++b)
+                    A->pix_counts[b].resize(pixSize[b]);
+                A->MatTrigFrame = trig0;
+                A->loc_thres = loc0;
+                A->TriggerFrameIdentificationStatus = status0;
+                A->okToProceed = ok0;
+                st_.needMore = true;
+                return;
+            }
             if (!A->okToProceed) {
                 st_.staged = A->TriggerFrameIdentificationStatus;
                 st_.done = true;
@@ -1027,6 +1299,9 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
                     }
                     // (-1 or an empty image = undecodable, like EventOnDevice; so is a frame of another size)
                     if (rc == -1 || img.empty() || img.cols != W || img.rows != H) {
+                        // (its slot would otherwise keep the bytes of an earlier batch: results never use them, but dense
+                        // garbage costs the trigger search's kernels time that varies from run to run)
+                        std::memset(h + ((size_t)s * Fmax + f) * P, 0, P);
                         ++bad;
                         continue;
                     }
@@ -1075,6 +1350,10 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
     auto worker = [&](int g) {
         uint8_t *h_slab[2] = {nullptr, nullptr}, *d_slab[2] = {nullptr, nullptr}, *d_model = nullptr;
         hipStream_t copyStream = nullptr;
+        // The look-ahead decode thread writes decd[] and reads nthr: both live OUTSIDE the try block, so that they outlive
+        // it on every failure path (the thread is joined below, after the catch).
+        Decoded decd[2];
+        const int nthr = std::max(1, ndec / ngpus);
         std::thread dec;
         try {
             const int dev = (opt.firstDevice + g) % ndev;
@@ -1098,8 +1377,6 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
             HIPOK(hipStreamSynchronize(copyStream));
             RunPipeline pipe(dev, W, H, Fmax, G, C, tss.data(), std::max(1, opt.hostThreads), opt.maskDir.c_str());
             pipe.d_sigmaRaw = d_sigma;
-            const int nthr = std::max(1, ndec / ngpus);
-            Decoded decd[2];
             int slot = 0;
             if (g < nb)
                 dec = std::thread([&, slot]() { decodeBatch(g, h_slab[slot], decd[slot], nthr); });
@@ -1116,6 +1393,9 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
                 const double dms = decd[slot].ms;
                 const long long good = decd[slot].ok, bad = decd[slot].bad;
                 pipe.setStackMeta(std::move(decd[slot].meta));
+                if (const char *tf = getenv("ABUB_TEST_FAIL_BATCH")) // test hook: a batch fails while the next one decodes
+                    if (atoi(tf) == b)
+                        throw std::runtime_error("injected failure of batch " + std::to_string(b) + " (ABUB_TEST_FAIL_BATCH)");
                 pipe.run(d_slab[slot], d_mu, d_s6, copyStream); // waits for the upload first
                 const double gms = nowMs() - tg;
                 double wms = 0;
@@ -1251,13 +1531,18 @@ void abh_pipe_desc(void *p, int s, int b, int d, double *out)
 float abh_pipe_dzdt(void *p, int s, int b) { return ((abub::RunPipeline *)p)->stacks[s].bubbles[b].dzdt; }
 float abh_pipe_drdt(void *p, int s, int b) { return ((abub::RunPipeline *)p)->stacks[s].bubbles[b].drdt; }
 const char *abh_pipe_stack_error(void *p, int s) { return ((abub::RunPipeline *)p)->stacks[s].error.c_str(); }
-// out[0..4]: stage1, stage2, stage3, stage4, total (ms) of the last run; returns the number of rounds
+// out[0..11]: stage1 .. stage4, total, stage-3 details (ms), candidate pairs, trigger-search jobs, drop-in stacks,
+// jobs completed on demand of the last run;
+// returns the number of rounds
 int abh_pipe_timing(void *p, double *out)
 {
     abub::RunPipeline *r = (abub::RunPipeline *)p;
     for (int k = 0; k < 8; ++k)
         out[k] = r->tms[k];
     out[8] = r->lastPairs;
+    out[9] = (double)r->jobsLaunched; // trigger-search jobs the run evaluated (S * (F - 1) when nothing is lazy)
+    out[10] = (double)r->dropIns;     // stacks re-run one at a time (bellows veto)
+    out[11] = (double)r->jobsCompleted; // trigger-search jobs whose dense rows were evaluated on demand (deferred pieces)
     return r->rounds;
 }
 }

@@ -104,16 +104,27 @@ def frame_noise(W, H, frame_seed, xp="numpy", device=None):
 class EventSpec:
     """What happens in one (event, camera) stack."""
 
-    def __init__(self, F, t0=None, bubbles=(), flicker=None, flicker_adu=3):
+    def __init__(self, F, t0=None, bubbles=(), flicker=None, flicker_adu=3, dense_from=None, hot_per_400=0):
         self.F = F
         self.t0 = t0            # genesis frame index (None: no bubble -> status -3)
         self.bubbles = list(bubbles)  # [(cx, cy, contrast)]
         self.flicker = flicker  # frame index with +flicker_adu on the whole frame, or None
         self.flicker_adu = flicker_adu
+        # "decompression": from this frame on 35 % of the image (a band of columns) carries the offsets +8, +8, -8, -8, +8, ..
+        # ADU, so that every such frame differs from the frame two before it by 16 ADU over that band.  The band is also
+        # livelier in the training frames (-2 in frame 0, +2 in frame 1: sigma = 2 there, 6 sigma = 12), so 16 ADU is more
+        # than 6 sigma -- dense work for the trigger search, if it ever looks there -- while |f - mu| = 8 stays below it:
+        # the tracking frames keep their one bubble (None: never)
+        self.dense_from = dense_from
+        # hot pixels: this many of every 400 pixels (fixed per camera) are exactly constant in frames 0 and 1 (the training
+        # frames: sigma = 0 there) and jitter by U{-3..3} in every later frame
+        self.hot_per_400 = hot_per_400
 
 
-def random_spec(W, H, F, event, cam, p_second=0.2, p_none=0.0, p_flicker=0.0, margin=40):
-    """Deterministic spec from (event, cam) -- host-side, tiny."""
+def random_spec(W, H, F, event, cam, p_second=0.2, p_none=0.0, p_flicker=0.0, margin=40, accept=None, regime="default"):
+    """Deterministic spec from (event, cam) -- host-side, tiny.  `accept(cx, cy)` (optional) rejects bubble positions
+    (e.g. outside the fiducial mask); `regime`: "default", "post_trigger_dense" (EventSpec.dense_from = t0 + 3) or
+    "noisy" (hot pixels at ten times the default's density of supra-threshold pixels)."""
     rs = np.random.RandomState((BASE_SEED + event * 1000 + cam) & 0x7FFFFFFF)
     if rs.rand() < p_none:
         return EventSpec(F)
@@ -122,14 +133,64 @@ def random_spec(W, H, F, event, cam, p_second=0.2, p_none=0.0, p_flicker=0.0, ma
     nb = 2 if rs.rand() < p_second else 1
     bubbles = []
     for _ in range(nb):
-        cx = int(rs.randint(margin, W - margin))
-        cy = int(rs.randint(margin, H - margin))
+        for _try in range(64):
+            cx = int(rs.randint(margin, W - margin))
+            cy = int(rs.randint(margin, H - margin))
+            if accept is None or accept(cx, cy):
+                break
         contrast = -40 if rs.rand() < 0.5 else 40
         bubbles.append((cx, cy, contrast))
     flicker = None
     if rs.rand() < p_flicker:
         flicker = int(rs.randint(3, max(4, t0 - 3))) if t0 > 6 else None
-    return EventSpec(F, t0, bubbles, flicker)
+    return EventSpec(F, t0, bubbles, flicker, dense_from=t0 + 3 if regime == "post_trigger_dense" else None,
+                     hot_per_400=11 if regime == "noisy" else 0)
+
+
+def camera_masks(W, H, cam):
+    """Synthetic masks in the shape of cam_masks/40l-19: a fiducial mask (non-zero inside an ellipse that covers about
+    80 % of the frame) for every camera and, for odd cameras (the ones that see the bellows), a bellows mask: a strip
+    over the lowest part of the frame, 12 % of its area.  -> (fiducial uint8 [H,W] of 0 / 255, bellows or None)."""
+    y, x = np.ogrid[:H, :W]
+    fid = (((2 * x - W) * (2 * x - W)) * (H * H) + ((2 * y - H) * (2 * y - H)) * (W * W) <= (W * W) * (H * H)) .astype(np.uint8) * 255
+    bel = None
+    if cam % 2 == 1:
+        bel = np.zeros((H, W), np.uint8)
+        bel[(H * 80) // 100:(H * 95) // 100, W // 10:(W * 9) // 10] = 255
+    return fid, bel
+
+
+def write_masks(maskdir, W, H, ncams):
+    """cam<N>_mask.bmp / cam<N>_bellows_mask.bmp as 1-bit BMP files (like the reference's cam0_mask.bmp) into `maskdir`
+    (with a trailing separator, as L3Localizer concatenates it); returns an accept(cam) -> (cx, cy) -> bool factory for
+    random_spec: bubbles only inside the fiducial ellipse and outside the bellows strip."""
+    import os
+
+    from PIL import Image
+
+    os.makedirs(maskdir, exist_ok=True)
+    masks = {}
+    for c in range(ncams):
+        fid, bel = camera_masks(W, H, c)
+        Image.fromarray(fid).convert("1").save(os.path.join(maskdir, f"cam{c}_mask.bmp"))
+        if bel is not None:
+            Image.fromarray(bel).convert("1").save(os.path.join(maskdir, f"cam{c}_bellows_mask.bmp"))
+        masks[c] = (fid, bel)
+
+    def accept_for(cam, margin=60):
+        fid, bel = masks[cam]
+
+        def accept(cx, cy):
+            # the whole tracked disc (radius <= ~20 px within the tracking window, plus the box centre) stays inside
+            for dx, dy in ((0, 0), (margin, 0), (-margin, 0), (0, margin), (0, -margin)):
+                xx, yy = min(max(cx + dx, 0), W - 1), min(max(cy + dy, 0), H - 1)
+                if not fid[yy, xx] or (bel is not None and bel[yy, xx]):
+                    return False
+            return True
+
+        return accept
+
+    return accept_for
 
 
 def render_event(W, H, spec, event, cam, xp="numpy", device=None, out=None, bg=None):
@@ -142,8 +203,19 @@ def render_event(W, H, spec, event, cam, xp="numpy", device=None, out=None, bg=N
     x = be.arange(W, device)[None, :]
     y = be.arange(H, device)[:, None]
     ev_seed = BASE_SEED + event * 1000 + cam
+    hot = None
+    if spec.hot_per_400:
+        hot = _hash32((((y * W + x) * 40503) & 0xFFFFFFFF) ^ _hash32_scalar(cam * 104729 + 17)) % 400 < spec.hot_per_400
     for f in range(spec.F):
-        v = bg + frame_noise(W, H, ev_seed * 131 + f, xp, device)
+        noise = frame_noise(W, H, ev_seed * 131 + f, xp, device)
+        if hot is not None:  # constant in the training frames, U{-3..3} afterwards
+            jit = _hash32((((y * W + x) * 2246822519) & 0xFFFFFFFF) ^ _hash32_scalar(ev_seed * 977 + f)) % 7 - 3
+            noise = be.where(hot, jit if f >= 2 else jit * 0, noise)
+        v = bg + noise
+        if spec.dense_from is not None and (f >= spec.dense_from or f < 2):
+            band = (x >= (W * 30) // 100) & (x < (W * 65) // 100) & (y >= 0)
+            off = (-2 if f == 0 else 2) if f < 2 else (8 if (f - spec.dense_from) % 4 < 2 else -8)
+            v = be.where(band, v + off, v)
         if spec.flicker is not None and f == spec.flicker:
             v = v + spec.flicker_adu
         if spec.t0 is not None and f >= spec.t0:

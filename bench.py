@@ -45,6 +45,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--threads", type=int, default=16, help="host threads of the per-event state machines")
+    ap.add_argument("--decode-threads", type=int, default=0,
+                    help="decode threads of the ingestion leg (0 = the cores this process may run on, at most 128)")
     ap.add_argument("--inflight", type=int, default=6,
                     help="steps in flight at once (each on its own pipeline object and host thread); measured on one MI355X: "
                          "2 -> 2.46, 3 -> 2.59, 4 -> 2.65, 6 -> 2.76, 8 -> 2.79, 12 -> 2.58 M frames/s")
@@ -58,7 +60,14 @@ def parse(argv=None):
     ap.add_argument("--max-blocks", type=int, default=400)
     ap.add_argument("--micro-frames", type=int, default=10000,
                     help="frames of the configs[2] kernel microbench slab (0 = skip)")
-    ap.add_argument("--ingest-events", type=int, default=24,
+    ap.add_argument("--regime-steps", type=int, default=12,
+                    help="steps per extra data regime (config.regimes: post_trigger_dense, noisy); 0 = skip")
+    ap.add_argument("--no-masks", action="store_true", help="run without fiducial / bellows mask files")
+    ap.add_argument("--slabs", type=int, default=0, help="copies of the run in HBM (0 = one per step in flight)")
+    ap.add_argument("--regime", default="default", choices=["default", "post_trigger_dense", "noisy"],
+                    help="data regime of the MAIN workload (default: BASELINE's quiet-noise run; the others are reported under "
+                         "config.regimes by the default run and can be made the main workload for A/B runs)")
+    ap.add_argument("--ingest-events", type=int, default=96,
                     help="events of the run written as a PNG zip archive on local disk and detected from there through the "
                          "batched ingestion path (decode-inclusive rate, config.ingest_inclusive; 0 = skip)")
     ap.add_argument("--latency-steps", type=int, default=5, help="steps run one at a time for the latency figure (0 = skip)")
@@ -73,6 +82,13 @@ def self_launch(args):
     Nothing here imports torch.cuda or calls HIP (a process that has initialised the GPU must not exec/fork workers)."""
     import socket
 
+    pre = os.environ.get("LD_PRELOAD", "") + " " + " ".join(k for k in os.environ if k.startswith(("ROCPROF", "ROCPROFILER")))
+    if "rocprof" in pre.lower():
+        # the profiler's preloaded library has initialised the GPU in THIS process already: starting rank processes from
+        # it is the launcher hop that must not follow GPU initialisation on this pool
+        print("bench.py: --gpus N > 1 under rocprofv3 is refused: profile a single rank (python3 bench.py without --gpus)",
+              file=sys.stderr)
+        sys.exit(2)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -193,25 +209,39 @@ def main():
 
         # ---- synthetic run, generated straight into HBM (rank r owns events r, r+N, r+2N, ...) ----------
         t0 = time.time()
-        slab = torch.empty((S, F, H, W), dtype=torch.uint8, device=dev)
+        import tempfile
+
+        # fiducial + bellows masks like cam_masks/40l-19 (BASELINE configs[1] runs with -m cam_masks): 1-bit BMP files in
+        # a temporary directory; bubbles are placed inside the fiducial region and outside the bellows strip
+        maskdir, accept_for = "", None
+        if not args.no_masks:
+            maskdir = tempfile.mkdtemp(prefix="abub_masks_") + "/"
+            accept_for = synth.write_masks(maskdir, W, H, C)
         bgs = [synth.background(W, H, synth.BASE_SEED + c, "torch", dev) for c in range(C)]
         ev_ids = shard.global_event_ids(E, rank, world)  # round-robin over ranks, like schedule(static,1)
-        for e in range(E):
-            ev = ev_ids[e]
+
+        def make_run(regime):
+            """-> (slab [S,F,H,W] in HBM, mu, sigma, sigma6) of one synthetic run in the given data regime"""
+            sl = torch.empty((S, F, H, W), dtype=torch.uint8, device=dev)
+            for e in range(E):
+                ev = ev_ids[e]
+                for c in range(C):
+                    spec = synth.random_spec(W, H, F, ev, c, p_second=0.2, accept=accept_for(c) if accept_for else None,
+                                             regime=regime)
+                    synth.render_event(W, H, spec, ev, c, xp="torch", device=dev, out=sl[e * C + c], bg=bgs[c])
+            # per-camera model from frames 0,1 of the first train-events events (K1 on the GPU)
+            mus, sgs = [], []
             for c in range(C):
-                spec = synth.random_spec(W, H, F, ev, c, p_second=0.2)
-                synth.render_event(W, H, spec, ev, c, xp="torch", device=dev, out=slab[e * C + c], bg=bgs[c])
-        # per-camera model from frames 0,1 of the first train-events events (K1 on the GPU)
-        mus, sgs = [], []
-        for c in range(C):
-            idx = torch.tensor([((e * C + c) * F + f) for e in range(min(args.train_events, E)) for f in (0, 1)],
-                               dtype=torch.int32, device=dev)
-            mu, sg = hip.train(slab, W, H, idx=idx)
-            mus.append(mu)
-            sgs.append(sg)
-        mu_d = torch.stack(mus).contiguous()
-        sg_d = torch.stack(sgs).contiguous()
-        s6_d = hip.sigma6(sg_d)
+                idx = torch.tensor([((e * C + c) * F + f) for e in range(min(args.train_events, E)) for f in (0, 1)],
+                                   dtype=torch.int32, device=dev)
+                mu, sg = hip.train(sl, W, H, idx=idx)
+                mus.append(mu)
+                sgs.append(sg)
+            mu_t = torch.stack(mus).contiguous()
+            sg_t = torch.stack(sgs).contiguous()
+            return sl, mu_t, sg_t, hip.sigma6(sg_t)
+
+        slab, mu_d, sg_d, s6_d = make_run(args.regime)
         torch.cuda.synchronize()
         gen_s = time.time() - t0
 
@@ -224,13 +254,20 @@ def main():
         # host threads per pipeline object: --threads each (the host stages sit on every step's critical path: 16 -> 2.75,
         # 8 -> 2.68, 5 -> 2.43 M frames/s at six steps in flight), but at most ~400 threads on the node over all ranks
         pipe_threads = args.pipe_threads if args.pipe_threads > 0 else min(max(1, args.threads), max(4, (400 // max(1, world)) // ninfl))
-        ring = host.PipelineRing(ninfl, local, W, H, F, E, C, tss, nthreads=pipe_threads)
+        ring = host.PipelineRing(ninfl, local, W, H, F, E, C, tss, nthreads=pipe_threads, maskdir=maskdir)
         pipes = ring.pipes
         pipe = pipes[0]
         stream = torch.cuda.current_stream().cuda_stream
+        for p_ in pipes:
+            p_.set_sigma(sg_d)  # (stacks that need the bellows veto are re-run one at a time and need sigma, not 6 sigma)
+        # one copy of the run per pipeline in flight: steps that overlap in time never read the same addresses
+        free_b, _ = torch.cuda.mem_get_info()
+        nslabs = max(1, min(args.slabs if args.slabs > 0 else ninfl, 1 + int((free_b * 0.8) // slab.numel())))
+        slabs = [slab] + [slab.clone() for _ in range(nslabs - 1)]
 
-        def run_steps(n):
-            return ring.run_batches([slab] * n, mu_d, s6_d, stream)
+        def run_steps(n, use=None):
+            sl = use if use is not None else slabs
+            return ring.run_batches([sl[k % len(sl)] for k in range(n)], mu_d, s6_d, stream)
 
         nwarm = max(args.warmup, ninfl if args.warmup else 0)  # every pipeline object of the ring gets one untimed step
         run_steps(nwarm)
@@ -238,7 +275,7 @@ def main():
 
     # ---- timed region: blocks of EXACTLY K steps, repeated until --min-seconds are on the clock ---------
     stage_keys = ("stage1_ms", "stage2_ms", "stage3_ms", "stage4_ms", "total_ms", "s3_gpu_ms", "s3_list_ms",
-                  "s3_bucket_ms", "pairs", "rounds")
+                  "s3_bucket_ms", "pairs", "trigger_jobs", "dropin_stacks", "jobs_completed_on_demand", "rounds")
     stage = {k: 0.0 for k in stage_keys}
     nstage = 0
     block_s, rank_block_s = [], []
@@ -280,6 +317,7 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "config": {
+            "regime": args.regime,
             "workload": f"synthetic 40l-19-like run: {E} events x {C} cams x {F} frames {W}x{H} u8 per GPU, HBM-resident; "
                         "per step: trigger search over every frame, genesis localisation, <=10-frame tracking, per-bubble records",
             "events_per_gpu": E, "cams": C, "frames_per_stack": F, "width": W, "height": H,
@@ -298,6 +336,21 @@ def main():
             "gen_seconds": round(gen_s, 1),
         },
     }
+    if not args.dry:
+        lazy = os.environ.get("ABUB_PIPE_LAZY", "1") != "0"
+        out["config"]["trigger_search"] = {
+            "lazy": lazy, "jobs_per_step": stage["trigger_jobs"] / max(1, nstage), "jobs_if_every_frame": S * (F - 1),
+            "note": "the reference walks a stack's frames in order and stops at the trigger (AnalyzerUnit.cpp:191, break at "
+                    ":307): the pipeline evaluates the frame differences block by block -- the first block (frames 1 .. F/2+4) "
+                    "for every stack, later blocks only for the stacks whose search reaches them (ABUB_PIPE_LAZY=0: every frame "
+                    "of every stack up front, round 2's behaviour); results are identical either way (tests)"}
+        out["config"]["slabs"] = {"copies_of_the_run_in_hbm": len(slabs), "bytes_each": slab.numel(),
+                                  "note": "step k reads copy k % copies: steps in flight at the same time never share addresses"}
+        out["config"]["masks"] = None if args.no_masks else {
+            "maskdir": "synthetic cam<N>_mask.bmp (fiducial ellipse, 79 % of the frame) for every camera and cam1_bellows_mask.bmp "
+                       "(strip, 12 % of the frame), 1-bit BMP like cam_masks/40l-19; bubbles are generated inside the fiducial "
+                       "region and outside the bellows strip",
+            "stacks_through_the_bellows_fallback_per_step": stage["dropin_stacks"] / max(1, nstage)}
     if args.dry:
         out["data"] = "none (dry protocol rehearsal, no kernels)"
         out["config"]["dry"] = True
@@ -364,6 +417,7 @@ def main():
         return sum(ts) / len(ts), ts[0]
 
     k2_ms, k2_min = time_launch(lambda: hip.diff_hist(slab, s6_d, jobs, W, H, store=False, hist=hist, chain=chain), kreps)
+    default_pieces, _ = hip.bound_counts()
     hist_h = hist.cpu()
     comp_bytes = 1.0 * P * njobs  # compulsory: every frame of a chain read once (the pass does not write D)
     alg_bytes = 3.0 * P * njobs   # SURVEY 8(d) accounting: cur, ref and sigma6 charged per job
@@ -381,9 +435,10 @@ def main():
                 traffic_src = os.path.relpath(cand, ROOT)
                 break
     out["roofline"] = {
-        "kernel": "K2 trigger-only pass (the pipeline's stage 1) = k2_bound_chain (dominant: bound scan + the waves' own "
-                  "exact tails) + k2_rows on handed-over rows + k_hist_bin0, timed together with HIP events on the launch stream: fused ProcessFrame + "
-                  "256-bin histogram of every frame pair of the run",
+        "kernel": "K2 trigger-only pass over EVERY frame of the run = k2_sad_chain (dominant: bound scan on v_sad_u8 group masses + "
+                  "the waves' own exact tails) + k2_rows on handed-over rows + k_hist_bin0, timed together with HIP events on the "
+                  "launch stream: fused ProcessFrame + 256-bin histogram of every frame pair of the run (the pipeline itself "
+                  "launches it block by block and skips the frames behind a stack's trigger: config.trigger_search)",
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
         "bytes_accounting": "compulsory: 1*W*H per job (each frame of a chain is read from HBM once; D is not written)",
@@ -399,7 +454,41 @@ def main():
         out["config"]["microbench"] = microbench(args, torch, hip, dev, W, H)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, np, torch, slab, mu_d, sg_d, hist_h, pipe, tss, S, F, C)
+        out["cpu_baseline"] = cpu_baseline(args, np, torch, slab, mu_d, sg_d, hist_h, pipe, tss, S, F, C,
+                                           None if args.no_masks else synth.camera_masks)
+
+    # ---- other data regimes (reported in config only): the same run with (a) everything behind the trigger dense
+    # ("decompression": 35 % of the image differs by > 6 sigma from frame t0 + 3 on) and (b) hot pixels at ten times the
+    # default's density of supra-threshold pixels; end-to-end rate, the K2 pass over EVERY frame alone, hand-over pieces
+    if args.regime_steps > 0 and rank == 0 and world == 1 and args.regime == "default":
+        out["config"]["regimes"] = {}
+        del slabs[1:]
+        for name in ("post_trigger_dense", "noisy"):
+            sl, mu_r, sg_r, s6_r = make_run(name)
+            for p_ in pipes:
+                p_.set_sigma(sg_r)
+            ring.run_batches([sl] * len(pipes), mu_r, s6_r, stream)  # every pipeline object once, untimed
+            torch.cuda.synchronize()
+            tr = time.perf_counter()
+            tms_r = ring.run_batches([sl] * args.regime_steps, mu_r, s6_r, stream)
+            torch.cuda.synchronize()
+            dt_r = (time.perf_counter() - tr) / args.regime_steps
+            fp_r = pipe.summary()
+            ms_all, _ = time_launch(lambda: hip.diff_hist(sl, s6_r, jobs, W, H, store=False, hist=hist, chain=chain), 4)
+            pieces, _ = hip.bound_counts()
+            out["config"]["regimes"][name] = {
+                "value_frames_per_s": S * F / dt_r, "ms_per_step": dt_r * 1e3, "steps": args.regime_steps,
+                "trigger_jobs_per_step": sum(t["trigger_jobs"] for t in tms_r) / len(tms_r),
+                "triggered_stacks": sum(1 for r in fp_r if r[0] == 0), "bubbles": sum(r[2] for r in fp_r),
+                "stage_ms": {k: round(sum(t[k] for t in tms_r) / len(tms_r), 3) for k in stage_keys},
+                "k2_pass_over_every_frame": {"ms": ms_all, "jobs": njobs, "handed_over_pieces_of_32_rows": pieces,
+                                             "frac_of_8TBps_compulsory": 1.0 * P * njobs / (ms_all * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+            }
+            del sl
+        out["config"]["regimes"]["default"] = {
+            "value_frames_per_s": out["value"], "ms_per_step": out["ms_per_step"],
+            "k2_pass_over_every_frame": {"ms": out["roofline"]["ms_per_launch"], "jobs": njobs,
+                                         "handed_over_pieces_of_32_rows": default_pieces}}
     if rank == 0:
         emit(out)
     if dist:
@@ -446,21 +535,23 @@ def ingest_inclusive(args, slab, pipe, E, C, F, W, H):
                 zbytes += len(data)
         t_make = time.perf_counter() - t0
         del blobs
-        nthr = min(args.threads, len(os.sched_getaffinity(0)))
-        t1 = time.perf_counter()
+        ncore = len(os.sched_getaffinity(0))
+        nthr = min(args.threads, ncore)                                          # host stages of the detect pipeline
+        ndec = args.decode_threads if args.decode_threads > 0 else min(ncore, 128)  # PNG decode (AutoBubStart3.cpp:338-342
+        t1 = time.perf_counter()                                                  # runs omp_get_max_threads() events at once)
         run = host.Run(kind="zip", run_folder=os.path.join(tmp, run_id))
         tr = [run.train(c, shape=(H, W)) for c in range(C)]
         t_train = time.perf_counter() - t1
         assert all(t[0] == 0 for t in tr), "training from the archive failed"
         t2 = time.perf_counter()
-        stats = run.run_batched(C, tmp + "/", run_id, 30, nthreads=nthr, decode_threads=nthr)
+        stats = run.run_batched(C, tmp + "/", run_id, 30, nthreads=nthr, decode_threads=ndec)
         t_detect = time.perf_counter() - t2
         run.close()
         nrows = sum(1 for _ in open(os.path.join(tmp, f"abub3hs_{run_id}.txt")))
         return {
             "frames_per_s": nev * C * F / t_detect, "frames": nev * C * F, "events": nev,
             "source": f"zip archive on local disk, {zbytes / 1e6:.0f} MB of 8-bit grey PNG (compress_level 1), ZipParser + own PNG decoder",
-            "decode_threads": nthr, "seconds": {"detect_total": t_detect, "list": stats["list_s"], "decode": stats["decode_s"],
+            "decode_threads": ndec, "host_threads": nthr, "cores_available": ncore, "seconds": {"detect_total": t_detect, "list": stats["list_s"], "decode": stats["decode_s"],
                                                 "upload_gpu_host_stages": stats["gpu_s"], "write": stats["write_s"],
                                                 "training_from_archive": t_train, "making_the_archive": t_make},
             "frames_per_s_decode_only": nev * C * F / max(stats["decode_s"], 1e-9),
@@ -550,7 +641,7 @@ def microbench(args, torch, hip, dev, W, H):
     return res
 
 
-def cpu_baseline(args, np, torch, slab, mu_d, sg_d, hist_h, pipe, tss, S, F, C):
+def cpu_baseline(args, np, torch, slab, mu_d, sg_d, hist_h, pipe, tss, S, F, C, masks_for=None):
     """CPU baseline = the oracle's whole detect path (AnyCamAnalysis restatement) on a bounded sample of the same
     stacks, 1 core.  It doubles as a full-size parity check of the GPU results."""
     from oracle import pyoracle as orc
@@ -560,11 +651,13 @@ def cpu_baseline(args, np, torch, slab, mu_d, sg_d, hist_h, pipe, tss, S, F, C):
     s_i = 0
     mu_h = mu_d.cpu().numpy()
     sg_h = sg_d.cpu().numpy()
+    H_, W_ = slab.shape[2], slab.shape[3]
+    mk = {c: (masks_for(W_, H_, c) if masks_for else (None, None)) for c in range(C)}
     while tcpu < args.cpu_seconds and s_i < S:
         st = slab[s_i].cpu().numpy()
         c = s_i % C
         tc = time.perf_counter()
-        a = orc.Analyzer(st, mu_h[c], sg_h[c], tss[c])
+        a = orc.Analyzer(st, mu_h[c], sg_h[c], tss[c], fid_mask=mk[c][0], bel_mask=mk[c][1])
         staged_r, state_r, bub_r = a.any_cam_analysis()
         tcpu += time.perf_counter() - tc
         a.close()
@@ -591,7 +684,7 @@ def cpu_baseline(args, np, torch, slab, mu_d, sg_d, hist_h, pipe, tss, S, F, C):
 
     def _one(item):
         st, c = item
-        a = orc.Analyzer(st, mu_h[c], sg_h[c], tss[c])  # ctypes drops the GIL inside the oracle
+        a = orc.Analyzer(st, mu_h[c], sg_h[c], tss[c], fid_mask=mk[c][0], bel_mask=mk[c][1])  # ctypes drops the GIL inside the oracle
         a.any_cam_analysis()
         a.close()
 

@@ -27,6 +27,10 @@ class OutputWriter {
     int NumCams;
 
 public:
+    // not in the reference: inserted before ".txt" in the output file name of every writer of this process (a sharded run
+    // -- `--gpu-shard r/N` -- writes abub3hs_<run>.part<r>of<N>.txt; `--merge N` assembles abub3hs_<run>.txt)
+    static std::string PartSuffix;
+
     struct BubbleData {
         std::vector<bubble *> BubbleObjectData; // borrowed: the analyzer owns the bubbles
         int StatusCode;

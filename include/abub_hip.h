@@ -125,6 +125,21 @@ int abub_diff_hist_chained_dev(const uint8_t *frames, const uint8_t *sigma6, con
 int abub_diff_hist_chained_store_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs, int njobs, int W,
                                      int H, uint32_t *hist, uint8_t *diff, int chain_len, int chain_stride, void *stream);
 
+/* Deferred pieces.  The trigger search stops at a stack's trigger frame (AnalyzerUnit.cpp:191, break at :307), but a batched
+ * launch covers whole blocks of frames before the host knows where that is.  abub_diff_hist_chained_deferred_dev() is
+ * abub_diff_hist_chained_dev() with the row machine left out: row ranges the bound scan hands over (dense frames) go to the
+ * caller's `pieces` list (abub_k2_pieces_cap(njobs, W, H) entries of 8 bytes, `*npieces` used) and incomplete[job] (njobs
+ * bytes) is set to 1 for every job that has some -- the histograms of exactly those jobs are not final.
+ * abub_diff_hist_pieces_dev() then runs the row machine on the pieces of the jobs with want[job] != 0 (njobs bytes) and
+ * finalises their histograms; same frames / sigma6 / jobs / njobs / hist as the deferred call.  A job must be completed at
+ * most once.  Needs abub_fast_path(W) and the "bound" option on. */
+size_t abub_k2_pieces_cap(int njobs, int W, int H);
+int abub_diff_hist_chained_deferred_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs, int njobs, int W,
+                                        int H, uint32_t *hist, int chain_len, int chain_stride, void *pieces,
+                                        uint32_t pieces_cap, uint32_t *npieces, uint8_t *incomplete, void *stream);
+int abub_diff_hist_pieces_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs, int njobs, int W, int H,
+                              uint32_t *hist, const void *pieces, const uint32_t *npieces, const uint8_t *want, void *stream);
+
 /* Run-time tuning knobs of the K2 launchers (defaults from ABUB_K2_BOUND / _CHAIN / _BUDGET / _PF / _SPLIT / _LIST / _WG /
  * _SYNC / _SCANPF in the environment):
  *   "bound"  1 = bound-and-verify pass (default), 0 = the plain row machine for every row (the dense-regime worst case)
@@ -144,6 +159,11 @@ int abub_k2_set_option(const char *name, int value);
  * library owns, one buffer per (device, stream), grown on demand.  Call this before destroying a stream that was
  * used for such launches (or at any quiet moment) to give its buffer back; it waits for the stream to drain. */
 int abub_scratch_release(void *stream);
+
+/* Diagnostics of the LAST bound-and-verify launch (K2 or K3) on `stream`, read back from that scratch buffer after the
+ * stream has drained: counts[0] = row pieces handed over to the row machine (32 rows each at most), counts[1] = entries
+ * of the global suspect list (0 when the scanning waves evaluate their own suspects).  Measurement only. */
+int abub_bound_counts_dev(void *stream, uint32_t counts[2]);
 int abub_diff_hist_compact_dev(const uint8_t *frames, const uint8_t *sigma6, const abub_job *jobs, int njobs,
                                int W, int H, uint32_t *hist, uint8_t *diff, const int32_t *cthr,
                                uint32_t *pairs, uint32_t cap, uint32_t *count, uint32_t slot_base,

@@ -36,6 +36,24 @@ def test_help_and_missing_arguments():
     assert rc == 255 and "Insufficient required arguments" in err  # main returns -1
 
 
+def test_merge_of_shard_part_files(tmp_path, oracle):
+    """--merge N (no GPU involved): N part files, shard r holding the blocks of events r, r + N, .. in order, become the
+    reference's one file in event order; blocks are runs of rows with the same event number, of any length."""
+    run_id, N = "20200925_0", 3
+    header = oracle.format_header()
+    blocks = ["".join(f"{run_id}  {100 + e}  {k}  row\n" for k in range(1 + e % 3)) for e in range(8)]
+    for r in range(N):
+        with open(os.path.join(tmp_path, f"abub3hs_{run_id}.part{r}of{N}.txt"), "w") as f:
+            f.write(header + "".join(blocks[r::N]))
+    rc, so, se = run_cli(["-r", run_id, "-o", str(tmp_path), "--merge", str(N)])
+    assert rc == 0, (so, se)
+    assert open(os.path.join(tmp_path, f"abub3hs_{run_id}.txt")).read() == header + "".join(blocks)
+    with open(os.path.join(tmp_path, f"abub3hs_{run_id}.part1of{N}.txt"), "w") as f:
+        f.write("another header\n" + "".join(blocks[1::N]))
+    rc, so, se = run_cli(["-r", run_id, "-o", str(tmp_path), "--merge", str(N)])
+    assert rc != 0 and "different header" in se
+
+
 def test_unreadable_zip_writes_minus5_rows(tmp_path):
     rc, out, _ = run_cli(["-z", "-d", str(tmp_path), "-r", "20200101_0", "-o", str(tmp_path)], env={"ABUB_NUM_CAMS": "2"})
     assert rc == 251  # -5
@@ -116,10 +134,21 @@ def test_cli_run_matches_oracle_text(tmp_path, oracle):
     # the reference's one-analyzer-at-a-time loop
     txt, so = cli("per_event", ["--per-event"])
     assert "batched detect" not in so and txt == expected
-    # events dealt to two shards (i % 2), each writes its own events in order
-    for r in (0, 1):
-        txt, _ = cli(f"shard{r}", ["--gpu-shard", f"{r}/2"])
-        assert txt == header + "".join(blocks[r::2]), r
+    # events dealt to three shards (i % 3): every shard writes its own part file in event order -- all into ONE output
+    # directory, as the ranks of a multi-GPU run would --, `--merge 3` assembles the reference's single ordered file
+    out = os.path.join(tmp_path, "out_sharded")
+    os.makedirs(out)
+    for r in (2, 0, 1):
+        rc, so, se = run_cli(["-d", data, "-r", run_id, "-o", out, "-D", "40l-19", "--gpu-shard", f"{r}/3"],
+                             env={"ABUB_THREADS": "4", "ABUB_NUM_CAMS": "2"})
+        assert rc == 0, (r, so[-2000:], se[-2000:])
+        assert open(os.path.join(out, f"abub3hs_{run_id}.part{r}of3.txt")).read() == header + "".join(blocks[r::3]), r
+    assert not os.path.exists(os.path.join(out, f"abub3hs_{run_id}.txt"))
+    rc, so, se = run_cli(["-r", run_id, "-o", out, "--merge", "3"])
+    assert rc == 0, (so, se)
+    assert open(os.path.join(out, f"abub3hs_{run_id}.txt")).read() == expected
+    rc, so, se = run_cli(["-r", run_id, "-o", out, "--merge", "4"])  # a part is missing
+    assert rc != 0 and "cannot read" in se
     # same run as a zip archive
     zpath = os.path.join(data, run_id + ".zip")
     with zipfile.ZipFile(zpath, "w", zipfile.ZIP_DEFLATED) as z:

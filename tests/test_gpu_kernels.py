@@ -517,6 +517,44 @@ def test_k2_chained_trigger_pass(oracle, W, H, F, off):
             assert np.array_equal(D.cpu().numpy(), Dref), (K, split, lst, wg, sync, pf, L, S)
 
 
+@pytest.mark.parametrize("W,H,F", [(1280, 96, 14), (1680, 64, 10), (512, 80, 9)])
+def test_k2_deferred_pieces(W, H, F):
+    """abub_diff_hist_chained_deferred_dev leaves the handed-over rows of dense frames to a later, per-job call: jobs it
+    does not flag have their final histograms at once; flagged jobs get theirs from abub_diff_hist_pieces_dev, in any
+    number of instalments; untouched flagged jobs stay partial.  Reference: the ordinary chained pass."""
+    nst = 3
+    spec = synth.EventSpec(F, t0=4, bubbles=[(W // 3, H // 2, 40)])
+    fr = torch.cat([synth.render_event(W, H, spec, 40 + s, 0, xp="torch", device=DEV) for s in range(nst)])
+    fr[F + 6] = torch.clamp(fr[F + 6].to(torch.int16) + 30, 0, 255).to(torch.uint8)      # a frame that differs everywhere
+    band = fr[2 * F + 5, 20:50].to(torch.int16)
+    band[:, ::2] += 25
+    fr[2 * F + 5, 20:50] = torch.clamp(band, 0, 255).to(torch.uint8)                     # a dense band inside a chunk
+    sg = torch.ones((1, H, W), dtype=torch.uint8, device=DEV)
+    s6 = hip.sigma6(sg)
+    jobs = hip.stack_jobs(nst, F, 1, F - 1, 2, 1, DEV)
+    ref, _ = hip.diff_hist(fr, s6, jobs, W, H, chain=(F - 1, 2))
+    hist, state = hip.diff_hist_deferred(fr, s6, jobs, W, H, chain=(F - 1, 2))
+    torch.cuda.synchronize()
+    inc = state[2].cpu().numpy().astype(bool)
+    assert int(state[1].item()) > 0 and inc.any() and not inc.all()
+    h = hist.cpu().numpy()
+    r = ref.cpu().numpy()
+    assert np.array_equal(h[~inc], r[~inc])                      # complete jobs: final
+    assert not np.array_equal(h[inc], r[inc])                    # the others really are partial
+    idx = np.flatnonzero(inc)
+    first, rest = idx[: len(idx) // 2], idx[len(idx) // 2:]
+    for part in (first, rest):
+        want = torch.zeros((jobs.shape[0],), dtype=torch.uint8, device=DEV)
+        want[torch.from_numpy(part).to(DEV)] = 1
+        hip.diff_hist_pieces(fr, s6, jobs, W, H, hist, state, want)
+        torch.cuda.synchronize()
+        h = hist.cpu().numpy()
+        assert np.array_equal(h[part], r[part])
+        if part is first and len(rest):
+            assert not np.array_equal(h[rest], r[rest])          # not asked for yet: untouched
+    assert np.array_equal(hist.cpu().numpy(), r)
+
+
 def test_scratch_release_and_reuse():
     """The trigger-only pass keeps its work list in library-owned scratch keyed by stream: releasing it (twice, and for
     a stream that never had one) is harmless, and the next launch on that stream allocates again and gives the same

@@ -187,6 +187,35 @@ def test_run_from_disk_equals_run_from_memory(tmp_path, oracle):
         assert out[e][0] == ref[0] and out[e][1] == ref[1]
 
 
+@pytest.mark.gpu
+def test_batched_run_survives_a_failing_batch(tmp_path, monkeypatch):
+    """RunBatched decodes batch b + 1 on a look-ahead thread while batch b is on the GPU.  When batch b fails, the
+    worker must join that thread before anything it writes to goes out of scope: the call returns an error, the process
+    stays healthy, and the same run then goes through and gives the same text as an undisturbed one."""
+    W, H, F = 320, 128, 20
+    rd, _ = make_run_dir(str(tmp_path), W=W, H=H, F=F, nev=8, ncams=1)
+
+    def go(outdir):
+        os.makedirs(outdir, exist_ok=True)
+        run = host.Run("raw", rd + "/", "Images")
+        try:
+            assert run.train(0, shape=(H, W))[0] == 0
+            return run.run_batched(1, outdir + "/", "r", 30, nthreads=4, decode_threads=4, batch_mb=1)
+        finally:
+            run.close()
+
+    st = go(os.path.join(str(tmp_path), "ok"))
+    assert st["batches"] >= 3
+    monkeypatch.setenv("ABUB_TEST_FAIL_BATCH", "0")
+    with pytest.raises(RuntimeError, match="injected failure"):
+        go(os.path.join(str(tmp_path), "fail"))
+    monkeypatch.delenv("ABUB_TEST_FAIL_BATCH")
+    go(os.path.join(str(tmp_path), "again"))
+    a = open(os.path.join(str(tmp_path), "ok", "abub3hs_r.txt")).read()
+    b = open(os.path.join(str(tmp_path), "again", "abub3hs_r.txt")).read()
+    assert a == b and len(a.splitlines()) >= 8
+
+
 @pytest.mark.parametrize("ext", ["png", "bmp"])
 def test_imwrite_round_trip(tmp_path, ext):
     """Debug image write-out (AnalyzerUnit.cpp:237, L3Localizer.cpp:236-257): what cvlite writes, Pillow and cvlite's

@@ -1,10 +1,12 @@
 #!/bin/bash
-# usage: tools_prof.sh <tag> [bench args...]   (run on the GPU box from the repo root)
+# usage: tools/prof_bench.sh <tag> [bench args...]   (run on the GPU box from the repo root; ONE rank only: no --gpus N > 1 --
+#        the profiler's preloaded library initialises the GPU before bench.py could start its ranks)
 # rocprofv3 kernel-trace + stats of bench.py; keeps only the small summaries under gpurun_out/<tag>/
 set -o pipefail
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1; shift
+case " $* " in *" --gpus "[2-9]*|*" --gpus="[2-9]*) echo "prof_bench.sh: profile a single rank (no --gpus N > 1 under rocprofv3)"; exit 2;; esac
 OUT=/tmp/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT $R/gpurun_out/$TAG
 cd /tmp

@@ -27,10 +27,14 @@ def main(d, out):
             kn = short(r["Kernel_Name"])
             per.setdefault(r["Counter_Name"], {}).setdefault(kn, []).append((int(r["Grid_Size"]), float(r["Counter_Value"])))
             meta.setdefault(kn, {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size")})
-    # the trigger-only pass: the chained scan's dispatches with the full-run grid, and the kernels launched with it
-    scan = [k for k in per.get("FETCH_SIZE", {}) if k.startswith("k2_bound_chain")]
+    missing = [c for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum") if c not in per]
+    if missing:
+        raise SystemExit(f"summarize_bench_pmc.py: counter(s) {missing} are missing in {d}: a pass failed; no summary")
+    # the trigger-only pass over every frame of the run (bench.py's roofline leg): the chained scan's dispatches with the
+    # largest grid, and the kernels launched with it
+    scan = [k for k in per.get("FETCH_SIZE", {}) if k.startswith("k2_sad_chain") or k.startswith("k2_bound_chain")]
     if not scan:
-        raise SystemExit("no k2_bound_chain dispatches in the counter files")
+        raise SystemExit("no chained-scan dispatches in the counter files")
     scan = scan[0]
     full_grid = max(g for g, _ in per["FETCH_SIZE"][scan])
     pass_kernels = {scan: full_grid}
