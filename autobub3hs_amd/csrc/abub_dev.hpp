@@ -79,6 +79,20 @@ __device__ __forceinline__ uint32_t widen_lo(uint32_t w) { return __builtin_amdg
 __device__ __forceinline__ uint32_t widen_hi(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c030c02u); }
 
 // hist[slot][0] = P - sum(hist[slot][1..255])  (the kernels only count non-zero pixels)
+// ---- packed-byte thresholds for the v_sad_u8 bound scans (K2: k2_sad_chain, K3: k3_bound_scan) ------------------------
+__device__ __forceinline__ uint32_t pk_addsat(uint32_t a, uint32_t b)
+{
+    u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(x, y));
+}
+// bytes (b0,b1) / (b2,b3) of a dword into the HIGH bytes of two u16 lanes: a saturating u16 add / sub of two such
+// values leaves min(x + y, 255) / max(x - y, 0) in the high byte
+__device__ __forceinline__ uint32_t widen8_lo(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x010c000cu); }
+__device__ __forceinline__ uint32_t widen8_hi(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x030c020cu); }
+// the high bytes of the lanes of (a: pixels 0,1; b: pixels 2,3) packed back into one dword
+__device__ __forceinline__ uint32_t pack8(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07050301u); }
+
+
 static __global__ __launch_bounds__(64) void k_hist_bin0(uint32_t *hist, uint32_t P, const uint8_t *__restrict__ only = nullptr)
 {
     if (only && !only[blockIdx.x]) // (deferred pieces: only the slots whose rows were just completed)

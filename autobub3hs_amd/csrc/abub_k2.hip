@@ -724,18 +724,6 @@ __global__ __launch_bounds__(64) void k2_bound_scan(const uint8_t *__restrict__ 
 // request hits the XCD's L2.  Measured: HBM traffic per job falls from 1.24 to 1.12 W*H, the pass
 // gets 2 - 20 % SLOWER -- the pass is bound by neither bytes nor VALU issue alone.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t pk_addsat(uint32_t a, uint32_t b)
-{
-    u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(x, y));
-}
-// bytes (b0,b1) / (b2,b3) of a dword into the HIGH bytes of two u16 lanes: a saturating u16 add / sub of two such
-// values leaves min(x + y, 255) / max(x - y, 0) in the high byte
-__device__ __forceinline__ uint32_t widen8_lo(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x010c000cu); }
-__device__ __forceinline__ uint32_t widen8_hi(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x030c020cu); }
-// the high bytes of the lanes of (a: pixels 0,1; b: pixels 2,3) packed back into one dword
-__device__ __forceinline__ uint32_t pack8(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07050301u); }
-
 template <int NDW, int K, bool SPLIT, int PF = 1>
 __global__ __launch_bounds__(64 * K2C_MAXW) void k2_sad_chain(const uint8_t *__restrict__ frames,
                                                    const uint8_t *__restrict__ sigma6,

@@ -286,7 +286,8 @@ __global__ __launch_bounds__(64) void k3_rows(const uint8_t *__restrict__ frames
 }
 
 // The K3 scan ("bound and verify", like K2's): KF consecutive jobs per wave, sharing the model rows.
-// O(y,x) != 0 needs a 3x3 sum S >= 5.  With the lane's pixels in 4-column groups taken in pairs (as in k2b_row), the
+// O(y,x) != 0 needs a 3x3 sum S >= 5.  Group masses come from v_sad_u8 on packed bytes (two per frame dword, the packed
+// thresholds shared by the wave's KF frames; see the loop).  With the lane's pixels in 4-column groups taken in pairs (as in k2b_row), the
 // box sums that touch a pair's columns in one row are bounded by M = left group + own pair + right group (edge groups
 // replicated: the reflected column lies inside them), and S <= M(y-1) + M(y) + M(y+1).  Rows where no pair reaches 5
 // are proven zero with one ballot (isolated hot pixels -- sigma = 0 leaves |f - mu| of a few ADU -- stay far below).
@@ -359,7 +360,6 @@ __global__ __launch_bounds__(64) void k3_bound_scan(const uint8_t *__restrict__ 
                                                     uint32_t budget, uint2 *__restrict__ glist,
                                                     uint32_t *__restrict__ gcount, uint32_t gcap)
 {
-    constexpr int NP = 2 * NDW;
     constexpr int NG = K3ScanJob<NDW>::NG, GS = K3ScanJob<NDW>::GS;
     __shared__ uint32_t pend[KF][K3S_PEND];
     const int lane = threadIdx.x;
@@ -434,22 +434,29 @@ __global__ __launch_bounds__(64) void k3_bound_scan(const uint8_t *__restrict__ 
             const int tt = t0 + u; // input row r = y0 - 1 + tt; completes the bound of output row y = y0 + tt - 2
             const int tn = tt + 1 < T ? tt + 1 : T - 1;
             K3S_LOAD(u ^ 1, reflect101(y0 - 1 + tn, H));
-            uint32_t HI[NP], LO[NP];
-            k3_thresholds<NDW>(raw[u][KF], raw[u][KF + 1], HI, LO);
+            // thresholds of this model row as packed bytes: HI = min(mu + sigma6, 255), LO = sat(mu - sigma6); then
+            //     2 * sum over a 4-pixel group of O = SAD(f, HI) + SAD(f, LO) - SAD(HI, LO)        (f inside [LO, HI]: the
+            // first two add up to HI - LO) -- exact, two v_sad_u8 per frame dword, the thresholds shared by the KF frames
+            uint32_t HI8[NDW], LO8[NDW], nS[NDW];
+#pragma unroll
+            for (int d = 0; d < NDW; d++) {
+                const uint32_t m0 = widen8_lo(raw[u][KF][d]), m1 = widen8_hi(raw[u][KF][d]);
+                const uint32_t s0 = widen8_lo(raw[u][KF + 1][d]), s1 = widen8_hi(raw[u][KF + 1][d]);
+                HI8[d] = pack8(pk_addsat(m0, s0), pk_addsat(m1, s1));
+                LO8[d] = pack8(pk_subsat(m0, s0), pk_subsat(m1, s1));
+                nS[d] = 0u - __builtin_amdgcn_sad_u8(HI8[d], LO8[d], 0u);
+            }
             const int y = y0 + tt - 2;
             const bool emit = tt >= 2 && tt < T;
 #pragma unroll
             for (int t = 0; t < KF; t++) {
                 if (t >= k)
                     continue;
-                // group masses of O in this input row (u16 halves: <= 2 * 255 each)
+                // twice the group masses of O in this input row (plain u32: <= 8 * 255 each)
                 uint32_t mg[NDW];
 #pragma unroll
-                for (int d = 0; d < NDW; d++) {
-                    const uint32_t f0 = widen_lo(raw[u][t][d]), f1 = widen_hi(raw[u][t][d]);
-                    mg[d] = (pk_subsat(f0, HI[2 * d]) | pk_subsat(LO[2 * d], f0)) +
-                            (pk_subsat(f1, HI[2 * d + 1]) | pk_subsat(LO[2 * d + 1], f1));
-                }
+                for (int d = 0; d < NDW; d++)
+                    mg[d] = __builtin_amdgcn_sad_u8(raw[u][t][d], LO8[d], __builtin_amdgcn_sad_u8(raw[u][t][d], HI8[d], nS[d]));
                 uint32_t mL = __builtin_amdgcn_update_dpp(0u, mg[NDW - 1], DPP_WAVE_SHR1, 0xf, 0xf, false);
                 uint32_t mR = __builtin_amdgcn_update_dpp(0u, mg[0], DPP_WAVE_SHL1, 0xf, 0xf, false);
                 mL = first_lane ? mg[0] : mL;
@@ -466,9 +473,9 @@ __global__ __launch_bounds__(64) void k3_bound_scan(const uint8_t *__restrict__ 
                     const uint32_t M = (g0 ? mg[g0 - 1] : mL) + own + (g1 + 1 < NDW ? mg[g1 + 1] : mR);
                     B[g] = M + J[t].Mh[u ^ 1][g] + J[t].Mh[u][g]; // rows r, r-1, r-2 (Mh[u] still holds row r-2)
                     J[t].Mh[u][g] = M;
-                    worst |= B[g];
+                    worst = B[g] > worst ? B[g] : worst;
                 }
-                const bool unsure = active && ((worst & 0xffffu) + (worst >> 16)) >= 5u; // (OR over-estimates: verified below)
+                const bool unsure = active && worst >= 10u; // S >= 5 <=> twice the mass bound >= 10
                 if (emit && y >= J[t].skipTo && __builtin_amdgcn_ballot_w64(unsure)) {
                     // ---- rare: some group of this output row cannot be proven zero ------------------------
                     unsigned long long bm[NG];
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(64) void k3_bound_scan(const uint8_t *__restrict__ 
                     uint32_t total = 0;
 #pragma unroll
                     for (int g = 0; g < NG; g++) {
-                        mine[g] = active && ((B[g] & 0xffffu) + (B[g] >> 16)) >= 5u;
+                        mine[g] = active && B[g] >= 10u;
                         bm[g] = __builtin_amdgcn_ballot_w64(mine[g]);
                         const int nq = GS * g + GS <= NDW ? GS : NDW - GS * g;
                         total += (uint32_t)nq * (uint32_t)__builtin_popcountll(bm[g]);

@@ -1,6 +1,8 @@
 // Parser base + MemParser (in-memory frame source).  See include/abub3hs/ParseFolder/Parser.hpp.
 #include "ParseFolder/Parser.hpp"
 
+#include <cstring>
+
 #include <algorithm>
 #include <cstdio>
 
@@ -36,6 +38,16 @@ void MemParser::AddNamedFrames(const std::string &EventID, int camera, const std
     for (size_t k = 0; k < names.size(); ++k)
         v.push_back(Frame{names[k], images && k < images->size() ? (*images)[k] : cv::Mat()});
     std::sort(v.begin(), v.end(), [](const Frame &a, const Frame &b) { return a.name < b.name; });
+}
+
+int Parser::GetImageInto(std::string EventID, std::string FrameName, unsigned char *dst, int W, int H)
+{
+    cv::Mat img;
+    const int rc = GetImage(EventID, FrameName, img);
+    if (rc == -1 || img.empty() || img.cols != W || img.rows != H)
+        return -1;
+    std::memcpy(dst, img.data, (size_t)W * H);
+    return 1;
 }
 
 int MemParser::GetImage(std::string EventID, std::string FrameName, cv::Mat &out)

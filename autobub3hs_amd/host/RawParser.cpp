@@ -38,6 +38,29 @@ int RawParser::GetImage(std::string EventID, std::string FrameName, cv::Mat &Ima
     return !Image.empty();
 }
 
+int RawParser::GetImageInto(std::string EventID, std::string FrameName, unsigned char *dst, int W, int H)
+{
+#ifdef ABUB_USE_OPENCV
+    return Parser::GetImageInto(EventID, FrameName, dst, W, H);
+#else
+    const std::string path = joinPath(joinPath(joinPath(RunFolder, EventID), ImageFolder), FrameName);
+    static thread_local std::vector<unsigned char> data; // keeps its capacity from frame to frame
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f)
+        return -1;
+    size_t n = 0;
+    if (fseeko(f, 0, SEEK_END) == 0) {
+        const off_t sz = ftello(f);
+        if (sz > 0 && fseeko(f, 0, SEEK_SET) == 0) {
+            data.resize((size_t)sz);
+            n = fread(data.data(), 1, (size_t)sz, f);
+        }
+    }
+    fclose(f);
+    return n && cv::imdecodeInto(data.data(), n, dst, W, H) ? 1 : -1;
+#endif
+}
+
 void RawParser::GetFileLists(const char *EventFolder, std::vector<std::string> &FileList, const char *camera_out_name)
 {
     DIR *dir = opendir(EventFolder);

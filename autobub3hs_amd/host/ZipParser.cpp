@@ -160,13 +160,14 @@ bool ZipParser::readEntry(int entry, std::vector<unsigned char> &out)
     if (!preadAll(fp, e.localHeaderOffset, lh, 30) || rd32(lh) != 0x04034b50u)
         return false;
     const uint64_t dataOff = e.localHeaderOffset + 30 + rd16(lh + 26) + rd16(lh + 28);
-    std::vector<unsigned char> comp(e.compressedSize);
+    if (e.method == 0) { // stored: straight into `out` (callers on the batched path pass a thread-local vector that keeps its capacity)
+        out.resize(e.compressedSize);
+        return !e.compressedSize || preadAll(fp, dataOff, out.data(), out.size());
+    }
+    static thread_local std::vector<unsigned char> comp;
+    comp.resize(e.compressedSize);
     if (e.compressedSize && !preadAll(fp, dataOff, comp.data(), comp.size()))
         return false;
-    if (e.method == 0) {
-        out.swap(comp);
-        return true;
-    }
     if (e.method != 8)
         return false;
     out.resize(e.uncompressedSize);
@@ -201,6 +202,25 @@ int ZipParser::GetImage(std::string EventID, std::string FrameName, cv::Mat &Ima
         return -1;
     }
     return 1;
+}
+
+int ZipParser::GetImageInto(std::string EventID, std::string FrameName, unsigned char *dst, int W, int H)
+{
+#ifdef ABUB_USE_OPENCV
+    return Parser::GetImageInto(EventID, FrameName, dst, W, H);
+#else
+    BuildFileList();
+    auto ev = index->ImageLocs.find(EventID);
+    if (ev == index->ImageLocs.end())
+        return -1;
+    auto fr = ev->second.find(FrameName);
+    if (fr == ev->second.end())
+        return -1;
+    static thread_local std::vector<unsigned char> data; // keeps its capacity from frame to frame
+    if (!readEntry(fr->second, data))
+        return 0;
+    return cv::imdecodeInto(data.data(), data.size(), dst, W, H) ? 1 : -1;
+#endif
 }
 
 void ZipParser::GetFileLists(const char *, std::vector<std::string> &, const char *) {} // empty upstream too (:241-244)

@@ -54,14 +54,24 @@ static std::string usage()
 
 static bool eventNameOrderSort(const std::string &a, const std::string &b) { return std::stoi(a) < std::stoi(b); }
 
-// cores this process may run on (cgroup / taskset aware), the reference's omp_get_max_threads() (AutoBubStart3.cpp:338)
+// cores this process may use: the affinity mask (taskset, cpuset) AND the cgroup's CPU quota (cpu.max: a container may see
+// 256 cores and be allowed 16 of them) -- the reference's omp_get_max_threads() (AutoBubStart3.cpp:338) sees only the former
 static int usableCores()
 {
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
     cpu_set_t set;
     CPU_ZERO(&set);
     if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0)
-        return CPU_COUNT(&set);
-    return (int)std::max(1u, std::thread::hardware_concurrency());
+        n = CPU_COUNT(&set);
+    std::ifstream q("/sys/fs/cgroup/cpu.max"); // cgroup v2: "<quota> <period>" or "max <period>"
+    std::string quota;
+    long long period = 0;
+    if (q >> quota >> period && quota != "max" && period > 0) {
+        const long long c = (atoll(quota.c_str()) + period - 1) / period;
+        if (c >= 1 && c < n)
+            n = (int)c;
+    }
+    return n;
 }
 
 // --merge N: the reference writes ONE file in event order (the `ordered` clause, AutoBubStart3.cpp:380-383).  Shard r of N

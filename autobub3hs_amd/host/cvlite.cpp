@@ -140,17 +140,27 @@ static inline int paeth(int a, int b, int c)
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
-static Mat decodePNG(const uchar *buf, size_t size)
+// Where a decoder puts its pixels: asked once, after the header, for a w x h byte image (row-major, pitch w); nullptr =
+// the caller does not want an image of that size.
+struct PixelSink {
+    uchar *(*get)(void *ctx, unsigned w, unsigned h);
+    void *ctx;
+};
+
+// PNG -> 8-bit grey.  The two large temporaries (concatenated IDAT data, inflated scanlines) are thread-local and keep
+// their capacity: a decode thread of the batched ingestion path allocates nothing per frame (per-frame megabyte
+// allocations -- mmap / munmap / page faults under one mm lock -- are what kept 128 decode threads at the rate of 16).
+static bool decodePNGTo(const uchar *buf, size_t size, PixelSink sink)
 {
-    Mat out;
     static const uchar sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (size < 8 + 25 || memcmp(buf, sig, 8) != 0)
-        return out;
+        return false;
     auto be32 = [&](size_t o) { return ((unsigned)buf[o] << 24) | ((unsigned)buf[o + 1] << 16) | ((unsigned)buf[o + 2] << 8) | (unsigned)buf[o + 3]; };
     unsigned w = 0, h = 0, depth = 0, ctype = 0, interlace = 0;
     uchar pal[256][3];
     int npal = 0;
-    std::vector<uchar> idat;
+    static thread_local std::vector<uchar> idat, raw;
+    idat.clear();
     size_t o = 8;
     bool haveHdr = false, end = false;
     while (!end && o + 12 <= size) {
@@ -158,7 +168,7 @@ static Mat decodePNG(const uchar *buf, size_t size)
         const uchar *type = buf + o + 4;
         const uchar *data = buf + o + 8;
         if (o + 12 + (size_t)len > size)
-            return out;
+            return false;
         if (!memcmp(type, "IHDR", 4) && len >= 13) {
             w = be32(o + 8);
             h = be32(o + 12);
@@ -183,7 +193,7 @@ static Mat decodePNG(const uchar *buf, size_t size)
         o += 12 + (size_t)len;
     }
     if (!haveHdr || w == 0 || h == 0 || interlace != 0 || idat.empty())
-        return out;
+        return false;
     int channels;
     switch (ctype) {
     case 0: channels = 1; break;
@@ -191,21 +201,24 @@ static Mat decodePNG(const uchar *buf, size_t size)
     case 3: channels = 1; break;
     case 4: channels = 2; break;
     case 6: channels = 4; break;
-    default: return out;
+    default: return false;
     }
     if (!(depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16))
-        return out;
+        return false;
     if ((ctype == 2 || ctype == 4 || ctype == 6) && depth < 8)
-        return out;
+        return false;
     if (ctype == 3 && depth == 16)
-        return out;
+        return false;
     const size_t bitsPerPixel = (size_t)channels * depth;
     const size_t rowBytes = ((size_t)w * bitsPerPixel + 7) / 8;
     const size_t bpp = bitsPerPixel >= 8 ? bitsPerPixel / 8 : 1; // filter distance
-    std::vector<uchar> raw((rowBytes + 1) * (size_t)h);
-    if (!inflateZlibStream(idat.data(), idat.size(), raw.data(), raw.size()))
-        return out;
-    out.create((int)h, (int)w, CV_8U);
+    if (raw.size() < (rowBytes + 1) * (size_t)h)
+        raw.resize((rowBytes + 1) * (size_t)h);
+    if (!inflateZlibStream(idat.data(), idat.size(), raw.data(), (rowBytes + 1) * (size_t)h))
+        return false;
+    uchar *const base = sink.get(sink.ctx, w, h);
+    if (!base)
+        return false;
     // grey / palette lookup tables (the frames of a run are 8-bit grey or 8-bit palettised: one table look-up per pixel)
     uchar lut[256];
     for (int v = 0; v < 256; ++v)
@@ -218,8 +231,8 @@ static Mat decodePNG(const uchar *buf, size_t size)
         const int ft = src[0];
         ++src;
         // the filter type is constant along a row: one tight loop per type (the row above is `up`, zeros for row 0)
-        uchar *rowOut = direct8 ? out.ptr<uchar>((int)y) : cur.data();
-        const uchar *up = y == 0 ? zero.data() : (direct8 ? out.ptr<uchar>((int)y - 1) : prev.data());
+        uchar *rowOut = direct8 ? (base + (size_t)y * w) : cur.data();
+        const uchar *up = y == 0 ? zero.data() : (direct8 ? (base + (size_t)(y - 1) * w) : prev.data());
         switch (ft) {
         case 0:
             std::memcpy(rowOut, src, rowBytes);
@@ -257,19 +270,18 @@ static Mat decodePNG(const uchar *buf, size_t size)
             }
             break;
         default:
-            out.release();
-            return out;
+            return false;
         }
         if (direct8)
             continue;
         if ((ctype == 0 || ctype == 3) && depth == 8) { // 8-bit palette (or grey through the identity table)
-            uchar *d8 = out.ptr<uchar>((int)y);
+            uchar *d8 = (base + (size_t)y * w);
             for (unsigned x = 0; x < w; ++x)
                 d8[x] = lut[cur[x]];
             prev.swap(cur);
             continue;
         }
-        uchar *dst = out.ptr<uchar>((int)y);
+        uchar *dst = (base + (size_t)y * w);
         for (unsigned x = 0; x < w; ++x) {
             if (ctype == 0 || ctype == 3) {
                 unsigned v;
@@ -296,7 +308,48 @@ static Mat decodePNG(const uchar *buf, size_t size)
         }
         prev.swap(cur);
     }
+    return true;
+}
+
+static uchar *matSink(void *ctx, unsigned w, unsigned h)
+{
+    Mat *m = (Mat *)ctx;
+    m->create((int)h, (int)w, CV_8U);
+    return m->data;
+}
+static Mat decodePNG(const uchar *buf, size_t size)
+{
+    Mat out;
+    PixelSink sink = {matSink, &out};
+    if (!decodePNGTo(buf, size, sink))
+        out.release();
     return out;
+}
+
+struct FixedDst {
+    uchar *dst;
+    unsigned w, h;
+};
+static uchar *fixedSink(void *ctx, unsigned w, unsigned h)
+{
+    FixedDst *f = (FixedDst *)ctx;
+    return (w == f->w && h == f->h) ? f->dst : nullptr;
+}
+// decodes straight into `dst` (W * H bytes); false when the data is not a W x H image this decoder reads
+bool imdecodeInto(const uchar *data, size_t size, uchar *dst, int W, int H)
+{
+    if (!data || !dst || W <= 0 || H <= 0)
+        return false;
+    if (size >= 8 && data[0] == 0x89 && data[1] == 'P') {
+        FixedDst f = {dst, (unsigned)W, (unsigned)H};
+        PixelSink sink = {fixedSink, &f};
+        return decodePNGTo(data, size, sink);
+    }
+    const Mat m = imdecode(data, size, 0); // (BMP: small files, decoded the ordinary way)
+    if (m.empty() || m.cols != W || m.rows != H)
+        return false;
+    std::memcpy(dst, m.data, (size_t)W * H);
+    return true;
 }
 
 Mat imdecode(const uchar *data, size_t size, int)

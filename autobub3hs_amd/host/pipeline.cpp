@@ -461,116 +461,124 @@ public:
         : device(device_), W(W_), H(H_), F(F_), E(E_), C(C_), S(E_ * C_), nthreads(nthreads_), P((size_t)W_ * H_),
           tss(tss_, tss_ + C_), maskDir(maskdir ? maskdir : "")
     {
-        if (W <= 0 || H <= 0 || F <= 0 || E <= 0 || C <= 0)
-            throw std::runtime_error("RunPipeline: bad geometry");
-        HIPOK(hipSetDevice(device));
-        const char *eg = getenv("ABUB_PIPE_GROUPS");
-        ngroups = eg ? atoi(eg) : 1; // >1 overlaps host stages of one group with the GPU work of the next
-        const char *eo = getenv("ABUB_PIPE_ORDERED");
-        ordered = eo ? atoi(eo) != 0 : true;
-        int prLow = 0, prHigh = 0; // (numerically lower = higher priority)
-        HIPOK(hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
-        HIPOK(hipStreamCreateWithPriority(&stage1Stream, hipStreamNonBlocking, prLow));
-        if (ngroups < 1)
-            ngroups = 1;
-        if (ngroups > S)
-            ngroups = S;
-        const int K = NumFramesBubbleTrack + 1;
-        chainStride = tss[0] < 6 ? 1 : 2;
-        for (int c = 1; c < C; ++c)
-            if ((tss[c] < 6 ? 1 : 2) != chainStride)
-                chainStride = 0;
-        groups.resize(ngroups);
-        pool.reset(new WorkerPool(std::max(0, nthreads - ngroups))); // the group driver threads take part too
-        // Frame blocks of the trigger search.  The reference walks the frames in order and stops at the trigger
-        // (AnalyzerUnit.cpp:191, break at :307); it never differences the frames behind it unless the localizer finds no
-        // bubble and the search goes on (AutoBubStart3.cpp:87-110).  So the histograms are produced block by block: block 0
-        // for every stack up front, later blocks only for the stacks whose search reaches them.  ABUB_PIPE_LAZY=0: one
-        // block (every frame of every stack up front, what round 2 did).
-        {
-            const char *el = getenv("ABUB_PIPE_LAZY");
-            const bool lazy = el ? atoi(el) != 0 : true;
-            const char *e0 = getenv("ABUB_PIPE_BLOCK0"), *e1 = getenv("ABUB_PIPE_BLOCK");
-            // first block: up to the frame the cameras' own trigger puts the bubble at (the middle of the stack) plus the
-            // two look-ahead frames and a margin; then blocks of about a fifth of the stack
-            int first = e0 && atoi(e0) > 0 ? atoi(e0) : F / 2 + 4, step = e1 && atoi(e1) > 0 ? atoi(e1) : std::max(4, F / 5);
-            blocks.clear();
-            blocks.push_back(1);
-            if (lazy && F > 8)
-                for (int b = std::min(first + 1, F); b < F && (int)blocks.size() < BatchEventData::MAXB; b += step)
-                    blocks.push_back(b);
-            blocks.push_back(std::max(F, 1)); // block k = frames [blocks[k], blocks[k + 1])
-            // Deferred pieces: inside a block the bound scan still covers every frame, but the row machine runs only on the
-            // dense frames a search actually reaches (ABUB_PIPE_DEFER=0: at once, for every frame of the block).
-            const char *ed = getenv("ABUB_PIPE_DEFER");
-            deferPieces = (ed ? atoi(ed) != 0 : true) && chainStride > 0 && abub_fast_path(W) != 0;
-        }
-        const int nB = (int)blocks.size() - 1;
-        for (int g = 0; g < ngroups; ++g) {
-            Group &G = groups[g];
-            G.s0 = (int)((long long)S * g / ngroups);
-            G.s1 = (int)((long long)S * (g + 1) / ngroups);
-            const size_t ns = (size_t)(G.s1 - G.s0), n3 = ns * K;
-            G.nthreads = std::max(1, nthreads / ngroups);
-            const char *ec = getenv("ABUB_PIPE_PAIRCAP"); // initial candidate-list capacity (grows on demand)
-            G.pairCap = ec && atoi(ec) > 0 ? (uint32_t)atoi(ec) : (8u << 20) / ngroups;
-            // the short localisation launches of a finished group must not queue behind the next group's
-            // chip-filling trigger search
-            HIPOK(hipStreamCreateWithPriority(&G.stream, hipStreamNonBlocking, prHigh));
-            HIPOK(hipEventCreateWithFlags(&G.stage1Done, hipEventDisableTiming));
-            HIPOK(hipEventCreateWithFlags(&G.kernelsDone, hipEventDisableTiming));
-            HIPOK(hipEventCreateWithFlags(&G.blockDone, hipEventDisableTiming));
-            G.usedB.assign(nB, 0);
-            for (int k = 0; k < nB; ++k) {
-                const size_t nj = ns * (size_t)std::max(blocks[k + 1] - blocks[k], 1);
-                G.d_jobsB.push_back(dalloc<abub_job>(nj));
-                G.h_jobsB.push_back(halloc<abub_job>(nj));
-                G.d_histB.push_back(dalloc<uint32_t>(nj * 256));
-                G.h_histB.push_back(halloc<uint32_t>(nj * 256));
-                // deferred pieces: at most H / 16 + 8 row ranges per job (chunks are at least 16 rows), 64 launches per block
-                const size_t pc = deferPieces ? nj * (size_t)(H / 16 + 8) : 1;
-                G.pieceCapB.push_back(pc);
-                G.d_piecesB.push_back((void *)dalloc<uint64_t>(pc));
-                G.d_pcountB.push_back(dalloc<uint32_t>(64));
-                G.d_incB.push_back(dalloc<uint8_t>(nj));
-                G.h_incB.push_back(halloc<uint8_t>(nj));
-                G.d_wantB.push_back(dalloc<uint8_t>(nj));
-                G.h_wantB.push_back(halloc<uint8_t>(nj));
+        try {
+            if (W <= 0 || H <= 0 || F <= 0 || E <= 0 || C <= 0)
+                throw std::runtime_error("RunPipeline: bad geometry");
+            HIPOK(hipSetDevice(device));
+            const char *eg = getenv("ABUB_PIPE_GROUPS");
+            ngroups = eg ? atoi(eg) : 1; // >1 overlaps host stages of one group with the GPU work of the next
+            const char *eo = getenv("ABUB_PIPE_ORDERED");
+            ordered = eo ? atoi(eo) != 0 : true;
+            int prLow = 0, prHigh = 0; // (numerically lower = higher priority)
+            HIPOK(hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
+            HIPOK(hipStreamCreateWithPriority(&stage1Stream, hipStreamNonBlocking, prLow));
+            if (ngroups < 1)
+                ngroups = 1;
+            if (ngroups > S)
+                ngroups = S;
+            const int K = NumFramesBubbleTrack + 1;
+            chainStride = tss[0] < 6 ? 1 : 2;
+            for (int c = 1; c < C; ++c)
+                if ((tss[c] < 6 ? 1 : 2) != chainStride)
+                    chainStride = 0;
+            groups.resize(ngroups);
+            pool.reset(new WorkerPool(std::max(0, nthreads - ngroups))); // the group driver threads take part too
+            // Frame blocks of the trigger search.  The reference walks the frames in order and stops at the trigger
+            // (AnalyzerUnit.cpp:191, break at :307); it never differences the frames behind it unless the localizer finds no
+            // bubble and the search goes on (AutoBubStart3.cpp:87-110).  So the histograms are produced block by block: block 0
+            // for every stack up front, later blocks only for the stacks whose search reaches them.  ABUB_PIPE_LAZY=0: one
+            // block (every frame of every stack up front, what round 2 did).
+            {
+                const char *el = getenv("ABUB_PIPE_LAZY");
+                const bool lazy = el ? atoi(el) != 0 : true;
+                const char *e0 = getenv("ABUB_PIPE_BLOCK0"), *e1 = getenv("ABUB_PIPE_BLOCK");
+                // first block: up to the frame the cameras' own trigger puts the bubble at (the middle of the stack) plus the
+                // two look-ahead frames and a margin; then blocks of about a fifth of the stack
+                int first = e0 && atoi(e0) > 0 ? atoi(e0) : F / 2 + 4, step = e1 && atoi(e1) > 0 ? atoi(e1) : std::max(4, F / 5);
+                blocks.clear();
+                blocks.push_back(1);
+                if (lazy && F > 8)
+                    for (int b = std::min(first + 1, F); b < F && (int)blocks.size() < BatchEventData::MAXB; b += step)
+                        blocks.push_back(b);
+                blocks.push_back(std::max(F, 1)); // block k = frames [blocks[k], blocks[k + 1])
+                // Deferred pieces: inside a block the bound scan still covers every frame, but the row machine runs only on the
+                // dense frames a search actually reaches (ABUB_PIPE_DEFER=0: at once, for every frame of the block).
+                const char *ed = getenv("ABUB_PIPE_DEFER");
+                deferPieces = (ed ? atoi(ed) != 0 : true) && chainStride > 0 && abub_fast_path(W) != 0;
             }
-            G.fetches.assign(nB, std::vector<Group::Fetch>());
-            G.pieceUsedB.assign(nB, 0);
-            G.d_jobs3 = dalloc<abub_job>(n3);
-            G.d_hist3 = dalloc<uint32_t>(n3 * 256);
-            G.d_img = dalloc<uint8_t>(abub_fast_path(W) ? 256 : n3 * P); // only the unfused fallback stores images
-            G.d_thr = dalloc<int32_t>(n3);
-            G.d_pairs = dalloc<uint32_t>((size_t)G.pairCap * 2);
-            G.d_count = dalloc<uint32_t>(1);
-            G.d_gscratch = dalloc<uint32_t>(2 * n3);
-            G.d_goff = dalloc<uint32_t>(n3 + 1);
-            G.d_gidx = dalloc<uint32_t>(G.pairCap);
-            G.d_gval = dalloc<uint8_t>(G.pairCap);
-            G.h_hist3 = halloc<uint32_t>(n3 * 256);
-            G.h_count = halloc<uint32_t>(1);
-            G.h_goff = halloc<uint32_t>(n3 + 1);
-            G.h_gidx = halloc<uint32_t>(G.pairCap);
-            G.h_gval = halloc<uint8_t>(G.pairCap);
-            G.h_jobs3 = halloc<abub_job>(n3);
-            G.h_thr = halloc<int32_t>(n3);
+            const int nB = (int)blocks.size() - 1;
+            for (int g = 0; g < ngroups; ++g) {
+                Group &G = groups[g];
+                G.s0 = (int)((long long)S * g / ngroups);
+                G.s1 = (int)((long long)S * (g + 1) / ngroups);
+                const size_t ns = (size_t)(G.s1 - G.s0), n3 = ns * K;
+                G.nthreads = std::max(1, nthreads / ngroups);
+                const char *ec = getenv("ABUB_PIPE_PAIRCAP"); // initial candidate-list capacity (grows on demand)
+                G.pairCap = ec && atoi(ec) > 0 ? (uint32_t)atoi(ec) : (8u << 20) / ngroups;
+                // the short localisation launches of a finished group must not queue behind the next group's
+                // chip-filling trigger search
+                HIPOK(hipStreamCreateWithPriority(&G.stream, hipStreamNonBlocking, prHigh));
+                HIPOK(hipEventCreateWithFlags(&G.stage1Done, hipEventDisableTiming));
+                HIPOK(hipEventCreateWithFlags(&G.kernelsDone, hipEventDisableTiming));
+                HIPOK(hipEventCreateWithFlags(&G.blockDone, hipEventDisableTiming));
+                G.usedB.assign(nB, 0);
+                for (int k = 0; k < nB; ++k) {
+                    const size_t nj = ns * (size_t)std::max(blocks[k + 1] - blocks[k], 1);
+                    G.d_jobsB.push_back(dalloc<abub_job>(nj));
+                    G.h_jobsB.push_back(halloc<abub_job>(nj));
+                    G.d_histB.push_back(dalloc<uint32_t>(nj * 256));
+                    G.h_histB.push_back(halloc<uint32_t>(nj * 256));
+                    // deferred pieces: at most H / 16 + 8 row ranges per job (chunks are at least 16 rows), 64 launches per block
+                    const size_t pc = deferPieces ? nj * (size_t)(H / 16 + 8) : 1;
+                    G.pieceCapB.push_back(pc);
+                    G.d_piecesB.push_back((void *)dalloc<uint64_t>(pc));
+                    G.d_pcountB.push_back(dalloc<uint32_t>(64));
+                    G.d_incB.push_back(dalloc<uint8_t>(nj));
+                    G.h_incB.push_back(halloc<uint8_t>(nj));
+                    G.d_wantB.push_back(dalloc<uint8_t>(nj));
+                    G.h_wantB.push_back(halloc<uint8_t>(nj));
+                }
+                G.fetches.assign(nB, std::vector<Group::Fetch>());
+                G.pieceUsedB.assign(nB, 0);
+                G.d_jobs3 = dalloc<abub_job>(n3);
+                G.d_hist3 = dalloc<uint32_t>(n3 * 256);
+                G.d_img = dalloc<uint8_t>(abub_fast_path(W) ? 256 : n3 * P); // only the unfused fallback stores images
+                G.d_thr = dalloc<int32_t>(n3);
+                G.d_pairs = dalloc<uint32_t>((size_t)G.pairCap * 2);
+                G.d_count = dalloc<uint32_t>(1);
+                G.d_gscratch = dalloc<uint32_t>(2 * n3);
+                G.d_goff = dalloc<uint32_t>(n3 + 1);
+                G.d_gidx = dalloc<uint32_t>(G.pairCap);
+                G.d_gval = dalloc<uint8_t>(G.pairCap);
+                G.h_hist3 = halloc<uint32_t>(n3 * 256);
+                G.h_count = halloc<uint32_t>(1);
+                G.h_goff = halloc<uint32_t>(n3 + 1);
+                G.h_gidx = halloc<uint32_t>(G.pairCap);
+                G.h_gval = halloc<uint8_t>(G.pairCap);
+                G.h_jobs3 = halloc<abub_job>(n3);
+                G.h_thr = halloc<int32_t>(n3);
+            }
+            // frame names only: the images live in HBM
+            for (int c = 0; c < C; ++c) {
+                Trainer *t = new Trainer(c, {}, "", "cam%d_image%u.png", "", parser.clone(), false);
+                t->TrainingSetSize = tss[c];
+                t->ModelId = 0;
+                trainers.push_back(t);
+            }
+            std::vector<cv::Mat> none((size_t)F);
+            for (int e = 0; e < E; ++e)
+                for (int c = 0; c < C; ++c)
+                    parser.AddFrames(std::to_string(e), c, none, 10000); // 5-digit numbers: lexicographic == numeric
+        } catch (...) { // (e.g. a hipMalloc that fails: give back what was allocated so far)
+            release();
+            throw;
         }
-        // frame names only: the images live in HBM
-        for (int c = 0; c < C; ++c) {
-            Trainer *t = new Trainer(c, {}, "", "cam%d_image%u.png", "", parser.clone(), false);
-            t->TrainingSetSize = tss[c];
-            t->ModelId = 0;
-            trainers.push_back(t);
-        }
-        std::vector<cv::Mat> none((size_t)F);
-        for (int e = 0; e < E; ++e)
-            for (int c = 0; c < C; ++c)
-                parser.AddFrames(std::to_string(e), c, none, 10000); // 5-digit numbers: lexicographic == numeric
     }
 
-    ~RunPipeline()
+    ~RunPipeline() { release(); }
+
+    // everything the object owns (also called by the constructor when it fails half-way: a destructor would not run)
+    void release() noexcept
     {
         (void)hipSetDevice(device);
         for (Group &G : groups) {
@@ -599,6 +607,12 @@ public:
             (void)hipHostFree(p);
         for (Trainer *t : trainers)
             delete t;
+        groups.clear();
+        copied.clear();
+        devAllocs.clear();
+        hostAllocs.clear();
+        trainers.clear();
+        stage1Stream = copyStream = nullptr;
     }
 
     // `callerStream`: work already queued there (e.g. the upload of the frames) is waited for first
@@ -1230,12 +1244,12 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
     st.Fmax = Fmax;
     const size_t perEvent = (size_t)C * Fmax * P;
     int G = (int)std::max<size_t>(1, std::min<size_t>(opt.batchBytes / perEvent, mine.size()));
-    // A run that would fit one or two batches is cut into at least four per GPU (of at least four events): decoding batch
-    // b + 1 then overlaps the GPU work of batch b, and the pinned slabs -- page-locking 2.6 GB takes about as long as
-    // decoding it on 16 threads -- are a quarter of the size.
+    // A run that would fit a few batches is cut into at least twelve per GPU (of at least four events): decoding batch
+    // b + 1 then overlaps the GPU work of batch b, and the two pinned slabs stay small -- page-locking 2.6 GB takes about
+    // as long as decoding it on 16 cores (measured: 1.0 s of a 2.8 s run of 96 events with batches of 24).
     {
         const int ng = std::max(1, opt.ngpus);
-        const int want = std::max(4, (int)((mine.size() + (size_t)4 * ng - 1) / ((size_t)4 * ng)));
+        const int want = std::max(4, (int)((mine.size() + (size_t)12 * ng - 1) / ((size_t)12 * ng)));
         G = std::max(1, std::min(G, want));
     }
     G = std::min(G, 512);
@@ -1290,22 +1304,21 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
                         break;
                     const int s = tasks[i].first, f = tasks[i].second;
                     StackMeta &m = out.meta[s];
-                    cv::Mat img;
+                    uint8_t *dst = h + ((size_t)s * Fmax + f) * P;
                     int rc = -1;
                     try {
-                        rc = p->GetImage(m.eventID, m.names[f], img);
+                        rc = p->GetImageInto(m.eventID, m.names[f], dst, W, H); // decoded in place, no per-frame allocation
                     } catch (...) {
                         rc = -1;
                     }
-                    // (-1 or an empty image = undecodable, like EventOnDevice; so is a frame of another size)
-                    if (rc == -1 || img.empty() || img.cols != W || img.rows != H) {
-                        // (its slot would otherwise keep the bytes of an earlier batch: results never use them, but dense
-                        // garbage costs the trigger search's kernels time that varies from run to run)
-                        std::memset(h + ((size_t)s * Fmax + f) * P, 0, P);
+                    // (anything but 1 = undecodable, like EventOnDevice; so is a frame of another size)
+                    if (rc != 1) {
+                        // (its slot would otherwise keep the bytes of an earlier batch or half a decode: results never use
+                        // them, but dense garbage costs the trigger search's kernels time that varies from run to run)
+                        std::memset(dst, 0, P);
                         ++bad;
                         continue;
                     }
-                    std::memcpy(h + ((size_t)s * Fmax + f) * P, img.data, P);
                     m.ok[f] = 1;
                     ++good;
                 }

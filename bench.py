@@ -114,6 +114,19 @@ def self_launch(args):
     sys.exit(rc)
 
 
+def usable_cores():
+    """Cores this process may use: the affinity mask AND the cgroup's CPU quota (a container may see 256 cores and be
+    allowed 16)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max" and int(period) > 0:
+            n = max(1, min(n, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def gather_floats(x, world, rank, dist):
     if not dist:
         return [x]
@@ -252,8 +265,12 @@ def main():
         # next.  Every step is still a full pass over the same batch, and all K of them complete inside the block.
         ninfl = max(1, args.inflight)
         # host threads per pipeline object: --threads each (the host stages sit on every step's critical path: 16 -> 2.75,
-        # 8 -> 2.68, 5 -> 2.43 M frames/s at six steps in flight), but at most ~400 threads on the node over all ranks
-        pipe_threads = args.pipe_threads if args.pipe_threads > 0 else min(max(1, args.threads), max(4, (400 // max(1, world)) // ninfl))
+        # 8 -> 2.68, 5 -> 2.43 M frames/s at six steps in flight), but at most two threads per usable core of this rank's share
+        # (per rank: the cores this process may run on, shared by the ranks of the node and the steps in flight)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        cores = usable_cores()
+        pipe_threads = args.pipe_threads if args.pipe_threads > 0 else min(max(1, args.threads),
+                                                                            max(4, (2 * cores // max(1, local_world)) // ninfl))
         ring = host.PipelineRing(ninfl, local, W, H, F, E, C, tss, nthreads=pipe_threads, maskdir=maskdir)
         pipes = ring.pipes
         pipe = pipes[0]
@@ -450,7 +467,9 @@ def main():
     }
 
     # ---- BASELINE configs[2]: the fused kernel on a contiguous 10k-frame slab, i = 2..F-1, ref = i-2 -------------
-    if args.micro_frames > 4 and rank == 0:
+    # (the single-GPU extras -- microbench, CPU baseline, regimes, ingestion -- run at N = 1 only: in a multi-rank run every
+    # rank is done at the same point and nobody waits for rank 0)
+    if args.micro_frames > 4 and rank == 0 and world == 1:
         out["config"]["microbench"] = microbench(args, torch, hip, dev, W, H)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -492,6 +511,7 @@ def main():
     if rank == 0:
         emit(out)
     if dist:
+        dist.barrier()  # all ranks leave together
         dist.destroy_process_group()
 
 
@@ -522,7 +542,7 @@ def ingest_inclusive(args, slab, pipe, E, C, F, W, H):
             Image.fromarray(frames[s, k]).save(b, format="PNG", compress_level=1)
             return s, k, b.getvalue()
 
-        with ThreadPoolExecutor(min(32, len(os.sched_getaffinity(0)))) as ex:
+        with ThreadPoolExecutor(min(32, usable_cores())) as ex:
             blobs = list(ex.map(enc, [(s, k) for s in range(nev * C) for k in range(F)]))
         zpath = os.path.join(tmp, run_id + ".zip")
         zbytes = 0
@@ -535,7 +555,7 @@ def ingest_inclusive(args, slab, pipe, E, C, F, W, H):
                 zbytes += len(data)
         t_make = time.perf_counter() - t0
         del blobs
-        ncore = len(os.sched_getaffinity(0))
+        ncore = usable_cores()
         nthr = min(args.threads, ncore)                                          # host stages of the detect pipeline
         ndec = args.decode_threads if args.decode_threads > 0 else min(ncore, 128)  # PNG decode (AutoBubStart3.cpp:338-342
         t1 = time.perf_counter()                                                  # runs omp_get_max_threads() events at once)
@@ -679,7 +699,7 @@ def cpu_baseline(args, np, torch, slab, mu_d, sg_d, hist_h, pipe, tss, S, F, C, 
     # AutoBubStart3.cpp:342): reported beside the 1-core figure, not instead of it
     from concurrent.futures import ThreadPoolExecutor
 
-    ncore = max(1, min(len(os.sched_getaffinity(0)), 32, S))
+    ncore = max(1, min(usable_cores(), 32, S))
     stacks_mc = [(slab[s].cpu().numpy(), s % C) for s in range(0, S, max(1, S // ncore))][:ncore]
 
     def _one(item):

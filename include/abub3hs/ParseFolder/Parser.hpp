@@ -28,6 +28,10 @@ public:
 
     // 1 = ok, -1 = missing / undecodable (the value the callers test, AnalyzerUnit.cpp:208, Trainer.cpp:262)
     virtual int GetImage(std::string EventID, std::string FrameName, cv::Mat &out) = 0;
+    // not in the reference: the same frame as 8-bit grey pixels written straight into `dst` (W * H bytes) -- what the batched
+    // ingestion path needs (no cv::Mat, no copy).  1 = ok; anything else (missing, undecodable, another size) = not written.
+    // The base implementation goes through GetImage(); RawParser / ZipParser decode in place with thread-local scratch.
+    virtual int GetImageInto(std::string EventID, std::string FrameName, unsigned char *dst, int W, int H);
     virtual void GetEventDirLists(std::vector<std::string> &EventList) = 0;
     virtual void GetFileLists(const char *EventFolder, std::vector<std::string> &FileList, const char *camera_out_name) = 0;
     // frame names of camera `camera` in event `EventID`, sorted lexicographically (RawParser.cpp:155)

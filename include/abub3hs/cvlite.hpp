@@ -147,6 +147,9 @@ enum { IMREAD_GRAYSCALE = 0 };
 Mat imread(const std::string &path, int flags = IMREAD_GRAYSCALE);
 Mat imdecode(const std::vector<uchar> &buf, int flags = IMREAD_GRAYSCALE);
 Mat imdecode(const uchar *data, size_t size, int flags = IMREAD_GRAYSCALE);
+// (not in OpenCV) decodes an 8-bit grey view of the image straight into `dst` (W * H bytes); false when the data is not a
+// W x H image; no per-call heap allocation for PNG (thread-local scratch)
+bool imdecodeInto(const uchar *data, size_t size, uchar *dst, int W, int H);
 // debug write-out (AnalyzerUnit.cpp:237,354-365; L3Localizer.cpp:236-257,448): 8-bit grey PNG, or 8-bit palettised BMP
 // when the name ends in .bmp; false when the file cannot be written (like cv::imwrite into a missing directory)
 bool imwrite(const std::string &path, const Mat &img);

@@ -255,6 +255,61 @@ def test_batched_pipeline_equals_oracle(oracle, W, H):
     pipe.close()
 
 
+@pytest.mark.parametrize("regime", ["default", "post_trigger_dense", "noisy"])
+def test_lazy_trigger_search_equals_oracle_in_every_regime(oracle, monkeypatch, regime):
+    """The pipeline's trigger search is lazy in two ways -- frame blocks evaluated on demand (ABUB_PIPE_LAZY / _BLOCK0 /
+    _BLOCK) and the row machine on dense frames only for the jobs a search reaches (ABUB_PIPE_DEFER).  Whatever the
+    combination, in quiet data, with everything behind the trigger dense, and with hot pixels everywhere (every frame
+    dense: every reached frame is completed on demand), the results are the oracle's."""
+    from autobub3hs_amd import hip
+
+    dev = "cuda:0"
+    W, H, F, E, C = 1280, 96, 41, 6, 2
+    slab = np.zeros((E, C, F, H, W), np.uint8)
+    for e in range(E):
+        for c in range(C):
+            spec = synth.random_spec(W, H, F, 700 + e, c, p_second=0.3, p_none=0.15, p_flicker=0.3, margin=25, regime=regime)
+            slab[e, c] = synth.render_event(W, H, spec, 700 + e, c)
+    models, tss = [], []
+    for c in range(C):
+        tr = np.concatenate([slab[e, c, :2] for e in range(E)])
+        models.append(oracle.welford(tr))
+        tss.append(len(tr))
+    refs = {(e, c): oracle_event(oracle, slab[e, c], models[c][0], models[c][1], tss[c]) for e in range(E) for c in range(C)}
+    d_slab = torch.from_numpy(slab).to(dev)
+    d_mu = torch.from_numpy(np.stack([m[0] for m in models])).to(dev)
+    d_s6 = hip.sigma6(torch.from_numpy(np.stack([m[1] for m in models])).to(dev))
+    seen_on_demand = False
+    for lazy, block0, block, defer in (("1", "", "", "1"), ("1", "12", "5", "1"), ("1", "12", "5", "0"), ("0", "", "", "1"),
+                                       ("0", "", "", "0"), ("1", "30", "4", "1")):
+        monkeypatch.setenv("ABUB_PIPE_LAZY", lazy)
+        monkeypatch.setenv("ABUB_PIPE_DEFER", defer)
+        for k, v in (("ABUB_PIPE_BLOCK0", block0), ("ABUB_PIPE_BLOCK", block)):
+            if v:
+                monkeypatch.setenv(k, v)
+            else:
+                monkeypatch.delenv(k, raising=False)
+        pipe = host.Pipeline(0, W, H, F, E, C, tss, nthreads=4)
+        pipe.run(d_slab, d_mu, d_s6, torch.cuda.current_stream().cuda_stream)
+        for e in range(E):
+            for c in range(C):
+                staged, state, bubbles, err = pipe.result(e * C + c)
+                ref = refs[(e, c)]
+                assert (staged, state) == (ref[0], ref[1]), (regime, lazy, block0, defer, e, c, staged, state, ref[0], ref[1], err)
+                assert [[tuple(d[k] for k in "xywh") for d in b["desc"]] for b in bubbles] == \
+                       [[tuple(d[k] for k in "xywh") for d in r["desc"]] for r in ref[2]]
+        t = pipe.timing()
+        if lazy == "0":
+            assert t["trigger_jobs"] == E * C * (F - 1)
+        elif block0 == "12":
+            assert t["trigger_jobs"] < E * C * (F - 1)
+        seen_on_demand = seen_on_demand or t["jobs_completed_on_demand"] > 0
+        if defer == "0":
+            assert t["jobs_completed_on_demand"] == 0
+        pipe.close()
+    assert seen_on_demand or regime != "noisy"  # (hot pixels everywhere: every reached frame had to be completed)
+
+
 def test_image_entropy_methods_free_function(oracle):
     import ctypes as C
 

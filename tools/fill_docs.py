@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Regenerates the measured-number blocks of DESIGN.md / README.md (between <!--gen:NAME--> ... <!--/gen:NAME-->)
-from the files under profiles/r02/, so the prose never quotes a number the committed evidence does not hold.
-Usage: python3 tools/fill_docs.py [profiles/r02]"""
+from the files under profiles/r03/, so the prose never quotes a number the committed evidence does not hold.
+Usage: python3 tools/fill_docs.py [profiles/r03]"""
 import csv
 import json
 import os
@@ -9,7 +9,8 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PROF = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "profiles/r02")
+PROF = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "profiles/r03")
+TAG = os.path.basename(PROF.rstrip("/"))
 
 
 def last_json(name):
@@ -36,19 +37,13 @@ def short(n):
 b = last_json("bench_default.json")
 q = last_json("bench_1680x1050.json")
 mb, mq = b["config"]["microbench"], q["config"]["microbench"]
-pm = {k: load(f"{k}_pmc_summary.json") for k in ("k2_hist", "k2_store", "k2_store_rowmachine", "k2_hist_1680")}
 bp, qp = load("bench_pmc_summary.json"), load("bench_1680x1050_pmc_summary.json")
 
 
-def mrow(label, m, key, pmc=None):
+def mrow(label, m, key):
     v = m[key]
-    extra = ""
-    if pmc is not None:
-        extra = f"{pmc['hbm_bytes_per_job_over_WH']:.2f}·W·H | {pmc['valu_insts_per_pixel_lane']:.1f}"
-    else:
-        extra = "— | —"
     return (f"| {label} | {v['ms_per_launch']:.2f} ms / {m['jobs_per_launch']} jobs | {v['us_per_job']:.3f} | "
-            f"{v['frac_of_8TBps']:.3f} | {extra} |")
+            f"{v['frac_of_8TBps']:.3f} | — | — |")
 
 
 def bench_row(label, r, p):
@@ -62,14 +57,16 @@ out = {}
 t = []
 t.append("| workload (kernel) | time per launch | µs / job | `frac` of 8 TB/s (compulsory bytes) | HBM traffic / job (PMC) | VALU / px |")
 t.append("|---|---|---|---|---|---|")
-t.append(bench_row("bench default, trigger pass of 200 stacks × 40 jobs, 1280×1024 (`k2_bound_chain<5,3,·,split>` + pieces) — `roofline`", b, bp))
-t.append(bench_row("bench `--width 1680 --height 1050`, same pass (`k2_bound_chain<7,2>` + pieces)", q, qp))
-t.append(mrow("BASELINE configs[2]: 10,000-frame 1280×1024 slab, **store mode** (D written; compulsory 2·W·H)", mb, "store_mode", pm["k2_store"]))
-t.append(mrow("same slab, trigger-only (compulsory 1·W·H)", mb, "trigger_only", pm["k2_hist"]))
-t.append(mrow("same slab, store mode, **row machine alone** (`bound = 0`: the dense-regime worst case)", mb, "store_mode_row_machine_only", pm["k2_store_rowmachine"]))
+t.append(bench_row("bench default, trigger pass over every frame: 200 stacks × 40 jobs, 1280×1024 (`k2_sad_chain<5,4,split,pf2>` + pieces) — `roofline`", b, bp))
+t.append(bench_row("bench `--width 1680 --height 1050`, same pass (`k2_sad_chain<7,4,split>` + pieces)", q, qp))
+t.append(mrow("BASELINE configs[2]: 10,000-frame 1280×1024 slab, **store mode** (D written; compulsory 2·W·H)", mb, "store_mode"))
+t.append(mrow("same slab, trigger-only (compulsory 1·W·H)", mb, "trigger_only"))
+t.append(mrow("same slab, store mode, **row machine alone** (`bound = 0`: the dense-regime worst case)", mb, "store_mode_row_machine_only"))
 t.append(mrow("same slab, trigger-only, row machine alone", mb, "trigger_only_row_machine_only"))
 t.append(mrow(f"{mq['frames']}-frame 1680×1050 slab, store mode", mq, "store_mode"))
-t.append(mrow(f"{mq['frames']}-frame 1680×1050 slab, trigger-only", mq, "trigger_only", pm["k2_hist_1680"]))
+t.append(mrow(f"{mq['frames']}-frame 1680×1050 slab, trigger-only", mq, "trigger_only"))
+
+
 # K3: the tracking frames' launch of the run pipeline (scan + suspect-list tail + handed-over pieces), one step in flight
 def k3_row(label, statsfile, p, W, H):
     k3 = p.get("k3")
@@ -93,37 +90,40 @@ for row in (k3_row("bench default, K3 over the tracking frames (`k3_bound_scan<5
         t.append(row)
 ca = b["roofline"]["contract_algorithmic"]
 t.append("")
-t.append(f"(PMC columns: `profiles/r02/*_pmc_summary.json`; the microbench PMC passes ran the native `tools/k2_microbench` on 2000 "
-         f"frames, the bench rows `rocprofv3 --pmc` around `python3 bench.py` itself.  HBM traffic above 1·W·H in "
-         f"trigger-only mode is the second and third read of a frame by the chunks' halo rows and by waves of other XCDs "
-         f"— L2 hit rate {bp['l2_hit_rate']:.2f} in the bench pass; `roofline.traffic` = {b['roofline']['traffic'] / 1e9:.1f} GB per launch "
-         f"against {b['roofline']['bytes_per_launch'] / 1e9:.1f} GB compulsory, `frac_of_traffic` "
-         f"{b['roofline'].get('frac_of_traffic', 0):.2f}.  In the SURVEY accounting the bench pass moves "
-         f"{ca['GBps'] / 1e3:.1f} TB/s — above the HBM peak, which is why it is not used as a fraction.)")
-# the chip's own streaming ceilings (hand-written flat kernels of tools/rowload_bench.cpp)
-flat_r, flat_c = [], []
-with open(os.path.join(PROF, "rowload.jsonl")) as f:
+t.append(f"(PMC columns: `profiles/{TAG}/*_pmc_summary.json`, `rocprofv3 --pmc` around `python3 bench.py` itself.  HBM traffic above "
+         f"1·W·H in trigger-only mode is the second read of the frame two neighbouring chain segments share and of the chunks' "
+         f"halo rows — L2 hit rate {bp['l2_hit_rate']:.2f} in the bench pass; `roofline.traffic` = "
+         f"{bp['hbm_bytes_per_launch'] / 1e9:.1f} GB per launch against {b['roofline']['bytes_per_launch'] / 1e9:.1f} GB compulsory.  In the "
+         f"SURVEY accounting the bench pass moves {ca['GBps'] / 1e3:.1f} TB/s — above the HBM peak, which is why it is not used as a fraction.)")
+# the chip's own copy / fill / read rates (tools/rowload_bench.cpp copy, the guide's shape)
+cp_rates, fill_rates, read_rates, flat = [], [], [], []
+memcpy_rate = memset_rate = None
+with open(os.path.join(PROF, "copy_ceiling.jsonl")) as f:
     for line in f:
         if not line.startswith("{"):
             continue
         d = json.loads(line)
-        if d.get("pattern") == "flat read":
-            flat_r.append(d["TBps"])
-        if d.get("pattern") == "flat copy":
-            flat_c.append(d["TBps_read_plus_write"])
-if flat_r and flat_c:
+        pt = d.get("pattern")
+        if pt == "guide copy":
+            cp_rates.append(d["TBps_read_plus_write"])
+        elif pt == "guide fill":
+            fill_rates.append(d["TBps"])
+        elif pt == "guide read":
+            read_rates.append(d["TBps"])
+        elif pt == "hipMemcpy D2D":
+            memcpy_rate = d["TBps_read_plus_write"]
+        elif pt == "hipMemset":
+            memset_rate = d["TBps"]
+if cp_rates:
     st = mb["store_mode"]["compulsory_GBps"] / 1e3
-    tr = mb["trigger_only"]["compulsory_GBps"] / 1e3
     t.append("")
-    t.append(f"For scale — what the chip gives kernels that do nothing else (`profiles/r02/rowload.jsonl`, 2.6 GB): a flat "
-             f"16-byte-per-lane **read {max(flat_r):.2f} TB/s** ({max(flat_r) / 8:.2f} of the 8 TB/s peak), a flat **copy "
-             f"{max(flat_c):.2f} TB/s** read + write ({max(flat_c) / 8:.2f}).  Store mode moves its compulsory bytes at "
-             f"{st:.2f} TB/s = **{st / max(flat_c):.2f} of the plain copy**; the trigger-only scan reads at {tr:.2f} TB/s = "
-             f"{tr / max(flat_r):.2f} of the flat read.")
-    pc = mb.get("plain_copy_same_bytes")
-    if pc:
-        t.append(f"(bench.py times torch's own device-to-device copy of the same bytes next to the store mode: "
-                 f"{pc['read_plus_write_GBps'] / 1e3:.2f} TB/s, store mode = {pc['store_mode_vs_copy']:.2f} of it.)")
+    t.append(f"For scale — what the chip gives kernels that do nothing else (`profiles/{TAG}/copy_ceiling.jsonl`, 2.6 GB, "
+             f"`tools/rowload_bench … copy`): a copy in the shape MI355X_MICROARCH.md quotes (4 – 8 independent 16-byte loads per "
+             f"lane in flight before the stores, contiguous tiles per workgroup) moves **{min(cp_rates):.2f} – {max(cp_rates):.2f} TB/s** "
+             f"read + write depending on grid size and nontemporal hints (the guide: 6.29; round 2's flat grid-stride copy: 4.6 – 4.8; "
+             f"`hipMemcpy` D2D {memcpy_rate:.2f}), a fill {min(fill_rates):.2f} – {max(fill_rates):.2f} TB/s (`hipMemset` {memset_rate:.2f}), "
+             f"a read {min(read_rates):.2f} – {max(read_rates):.2f} TB/s.  Store mode moves its compulsory 2·W·H per job at "
+             f"{st:.2f} TB/s = **{st / max(cp_rates):.2f} of the best copy**.")
 out["ROOFLINE_TABLE"] = "\n".join(t)
 
 tm = b["config"]["timing"]
@@ -152,7 +152,7 @@ for r in trace:
         break
     if n.startswith(("k1_", "k1b_", "k_sigma6")):
         continue  # training, once per run
-    if n.startswith("k2_bound_chain"):
+    if n.startswith("k_slot_counts_from_hist"):  # once per step (stage 3)
         nsteps += 1
     us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     per[n] = per.get(n, 0) + us
@@ -166,11 +166,29 @@ out["GPU_BREAKDOWN"] = (f"{tot / 1e3:.2f} ms of kernels per step — " +
                         f"{100 * tot / 1e3 / b['ms_per_step']:.0f} % of the step time (launch gaps, the candidate-list copies and "
                         f"the host stages that the other steps in flight do not hide make up the rest).")
 
+rgs = b["config"].get("regimes", {})
+rq = q["config"].get("regimes", {})
+if rgs:
+    out["REGIME_TEXT"] = "; ".join(
+        f"`{k}` {v['value_frames_per_s'] / 1e6:.2f} M frames/s ({v['ms_per_step']:.2f} ms per step; the K2 pass over every frame "
+        f"{v['k2_pass_over_every_frame']['ms']:.2f} ms with {v['k2_pass_over_every_frame']['handed_over_pieces_of_32_rows']} handed-over pieces"
+        + (f"; at 1680×1050 {rq[k]['value_frames_per_s'] / 1e6:.2f} M frames/s" if k in rq else "") + ")"
+        for k, v in rgs.items() if k != "default") + "."
+fz = os.path.join(PROF, "fuzz.txt")
+if os.path.exists(fz):
+    out["FUZZ_TEXT"] = open(fz).read().strip()
+
 cb = b["cpu_baseline"]
 rn = []
-rn.append(f"* end to end (BASELINE configs[1], frames resident in HBM): **{b['value'] / 1e6:.2f} M frames/s** on one GPU "
-          f"({b['ms_per_step']:.2f} ms per 8200-frame step); CPU oracle {cb['value']:.0f} frames/s on 1 core, "
-          f"{cb['all_cores']['value']:.0f} on {cb['all_cores']['cores']} threads.")
+ts = b["config"]["trigger_search"]
+rg = b["config"].get("regimes", {})
+rn.append(f"* end to end (BASELINE configs[1], frames resident in HBM, masks on): **{b['value'] / 1e6:.2f} M frames/s** on one GPU "
+          f"({b['ms_per_step']:.2f} ms per 8200-frame step; the trigger search evaluates {ts['jobs_per_step']:.0f} of "
+          f"{ts['jobs_if_every_frame']} frame differences: it stops where the reference stops); CPU oracle {cb['value']:.0f} frames/s on "
+          f"1 core, {cb['all_cores']['value']:.0f} on {cb['all_cores']['cores']} threads.")
+if rg:
+    rn.append("* other data regimes, same run: " + ", ".join(
+        f"`{k}` {v['value_frames_per_s'] / 1e6:.2f} M frames/s" for k, v in rg.items() if k != "default") + ".")
 rn.append(f"* trigger pass (dominant kernel): {b['roofline']['ms_per_launch']:.2f} ms per 8000 1280×1024 jobs = "
           f"`roofline.frac` {b['roofline']['frac']:.2f} of 8 TB/s on compulsory bytes.")
 rn.append(f"* BASELINE configs[2] (10,000-frame slab): D written {mb['store_mode']['us_per_job']:.3f} µs/job "
