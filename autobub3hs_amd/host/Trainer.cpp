@@ -6,8 +6,11 @@
 
 #include <atomic>
 #include <cstdio>
+#include <exception>
 #include <iostream>
+#include <memory>
 #include <stdexcept>
+#include <thread>
 
 #include "devctx.hpp"
 #include "hostlogic.hpp"
@@ -99,17 +102,65 @@ void Trainer::MakeAvgSigmaImage(bool PerformLBPOnImages)
     isLBPApplied = PerformLBPOnImages; // LBP path is dead code upstream (only `false` is ever passed)
     std::vector<cv::Mat> training;
     printf("Camera %d training ... ", camera);
+    // The training frames of every event (Trainer.cpp:248-276) are listed first and decoded by a few threads, each with its
+    // own Parser clone (the reference decodes them one after the other; the cameras already train side by side,
+    // AutoBubStart3.cpp:304-307); everything after that -- messages, entropy veto, the order of the training set -- runs
+    // in event order as upstream.
+    struct Wanted {
+        std::vector<std::string> frames;
+        std::vector<cv::Mat> img;
+        std::vector<int> err;
+        std::exception_ptr thrown; // re-thrown in event order below, where the sequential loop would have met it
+    };
+    std::vector<Wanted> wanted(EventList.size());
     for (size_t e = 0; e < EventList.size(); ++e) {
-        CameraFrames.clear();
-        FileParser->ParseAndSortFramesInFolder(EventList[e], camera, CameraFrames);
+        FileParser->ParseAndSortFramesInFolder(EventList[e], camera, wanted[e].frames);
+        wanted[e].img.resize(TrainingSequence.size());
+        wanted[e].err.assign(TrainingSequence.size(), -1);
+    }
+    {
+        unsigned nthr = std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 4));
+        if (const char *t = getenv("ABUB_TRAIN_THREADS"))
+            nthr = (unsigned)std::max(1, atoi(t));
+        nthr = (unsigned)std::min<size_t>(nthr, std::max<size_t>(1, EventList.size()));
+        std::atomic<size_t> next{0};
+        auto work = [&](Parser *p) {
+            for (;;) {
+                const size_t e = next.fetch_add(1);
+                if (e >= EventList.size())
+                    break;
+                for (size_t q = 0; q < TrainingSequence.size(); ++q) {
+                    const int which = TrainingSequence[q];
+                    try {
+                        wanted[e].err[q] = which < (int)wanted[e].frames.size()
+                                               ? p->GetImage(EventList[e], wanted[e].frames[which], wanted[e].img[q])
+                                               : -1;
+                    } catch (...) {
+                        wanted[e].thrown = std::current_exception();
+                        break;
+                    }
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        std::vector<std::unique_ptr<Parser>> clones;
+        for (unsigned t = 1; t < nthr; ++t) {
+            clones.emplace_back(FileParser->clone());
+            th.emplace_back(work, clones.back().get());
+        }
+        work(FileParser);
+        for (auto &t : th)
+            t.join();
+    }
+    for (size_t e = 0; e < EventList.size(); ++e) {
+        if (wanted[e].thrown)
+            std::rethrow_exception(wanted[e].thrown);
         std::vector<cv::Mat> pair;
         bool good = true;
-        if (!CameraFrames.empty()) {
-            for (int which : TrainingSequence) {
-                cv::Mat img;
-                int err = (which < (int)CameraFrames.size()) ? FileParser->GetImage(EventList[e], CameraFrames[which], img) : -1;
-                if (err != -1 && !img.empty())
-                    pair.push_back(img);
+        if (!wanted[e].frames.empty()) {
+            for (size_t q = 0; q < TrainingSequence.size(); ++q) {
+                if (wanted[e].err[q] != -1 && !wanted[e].img[q].empty())
+                    pair.push_back(wanted[e].img[q]);
                 else {
                     std::cout << "Skipping corrupted image for training.\n";
                     good = false;
@@ -131,7 +182,7 @@ void Trainer::MakeAvgSigmaImage(bool PerformLBPOnImages)
         if (entropy <= 0.0005 && good)
             for (cv::Mat &m : pair)
                 training.push_back(m);
-        CameraFrames.clear();
+        wanted[e].img.clear(); // (vetoed frames are released at once)
     }
     if (training.empty()) {
         std::cout << "Training image set for camera " << camera << " has 0 frames. This means that the event is malformed." << std::endl;

@@ -39,12 +39,23 @@ def case(rs):
     sg = torch.randint(0, 3, (2, H, W), device=DEV, dtype=torch.uint8)
     s6 = hip.sigma6(sg)
     jobs = hip.stack_jobs(nst, F, 1, F - 1, off, 2, DEV)
+    hip.k2_set_option("bound", 0)  # the reference of this tool: the plain row machine, storing every pixel
     ref, D = hip.diff_hist(fr, s6, jobs, W, H, store=True)
-    outs = {"plain": hip.diff_hist(fr, s6, jobs, W, H)[0]}
+    hip.k2_set_option("bound", 1)
+    sh, sD = hip.diff_hist(fr, s6, jobs, W, H, store=True)  # store mode of the bound-and-verify pass (fill + non-zero pixels)
+    assert torch.equal(sD, D), ("store image", W, H, nst, F, off, dens)
+    outs = {"store": sh, "plain": hip.diff_hist(fr, s6, jobs, W, H)[0]}
     if F > 1:
         outs["chain"] = hip.diff_hist(fr, s6, jobs, W, H, chain=(F - 1, off))[0]
         outs["chain-wrong-stride"] = hip.diff_hist(fr, s6, jobs, W, H, chain=(F - 1, off % 3 + 1))[0]
         outs["chain-one-block"] = hip.diff_hist(fr, s6, jobs, W, H, chain=(nst * (F - 1), off))[0]
+        # deferred form: the scan alone, then the row machine on a random subset of the jobs it flagged
+        dh, st = hip.diff_hist_deferred(fr, s6, jobs, W, H, chain=(F - 1, off))
+        inc = st[2].clone()
+        want = (torch.rand(inc.shape, device=DEV) < 0.5).to(torch.uint8)
+        hip.diff_hist_pieces(fr, s6, jobs, W, H, dh, st, want)
+        final = (inc == 0) | (want != 0)
+        assert torch.equal(dh[final], ref[final]), ("deferred", W, H, nst, F, off, dens)
     torch.cuda.synchronize()
     chk = torch.stack([torch.bincount(D[j].flatten().to(torch.int64), minlength=256) for j in range(min(3, D.shape[0]))])
     assert torch.equal(chk.to(ref.dtype), ref[:chk.shape[0]]), ("store hist != bincount(D)", W, H)

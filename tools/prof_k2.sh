@@ -13,7 +13,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_A
   rm -rf /tmp/pmc_$name
   timeout -k 10 200 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d /tmp/pmc_$name -- $R/tools/k2_microbench $F 2 $ST $EXTRA > $O/pmc_$name.log 2>&1 || { echo "pmc pass $name failed"; tail -3 $O/pmc_$name.log; continue; }
   for f in $(find /tmp/pmc_$name -name '*counter_collection.csv'); do
-    head -1 $f > $O/pmc_$name.csv; grep -E "k2_rows|k2_bound_scan|k2_bound_chain|k2_exact_groups" $f >> $O/pmc_$name.csv
+    head -1 $f > $O/pmc_$name.csv; grep -E "k2_rows|k2_bound_scan|k2_sad_chain|sus_tail" $f >> $O/pmc_$name.csv
   done
 done
 ls -la $O
