@@ -444,13 +444,15 @@ def main():
     traffic, traffic_src = None, None
     prof_root = os.path.join(ROOT, "profiles")
     for d in sorted((d for d in os.listdir(prof_root) if os.path.isdir(os.path.join(prof_root, d))), reverse=True):
-        cand = os.path.join(prof_root, d, "bench_pmc_summary.json")
-        if os.path.exists(cand):
+        for name in sorted(n for n in os.listdir(os.path.join(prof_root, d)) if n.startswith("bench") and n.endswith("pmc_summary.json")):
+            cand = os.path.join(prof_root, d, name)
             pm = json.load(open(cand))
             if pm.get("W") == W and pm.get("H") == H and pm.get("jobs_per_launch") == njobs:
                 traffic = pm["hbm_bytes_per_launch"]
                 traffic_src = os.path.relpath(cand, ROOT)
                 break
+        if traffic is not None:
+            break
     out["roofline"] = {
         "kernel": "K2 trigger-only pass over EVERY frame of the run = k2_sad_chain (dominant: bound scan on v_sad_u8 group masses + "
                   "the waves' own exact tails) + k2_rows on handed-over rows + k_hist_bin0, timed together with HIP events on the "
