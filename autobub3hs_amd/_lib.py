@@ -46,6 +46,8 @@ SIGNATURES = {
     "abub_diff_hist_chained_store_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "abub_k2_set_option": (_i, [C.c_char_p, _i]),
     "abub_k2_pieces_cap": (_sz, [_i, _i, _i]),
+    "abub_png_raw_stride": (_sz, [_i, _i]),
+    "abub_png_decode_dev": (_i, [_vp, _sz, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp]),
     "abub_diff_hist_chained_deferred_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, C.c_uint32, _vp, _vp, _vp]),
     "abub_diff_hist_pieces_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "abub_diff_hist_compact_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp]),

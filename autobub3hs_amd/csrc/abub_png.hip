@@ -1,0 +1,928 @@
+// abub_png.hip -- the frames of a run decoded ON the GPU: PNG (8-bit grey or 8-bit palette, non-interlaced) -> u8 frames
+// in the slab the trigger search reads.  Replaces, for the batched ingestion path, the per-frame host decode behind
+// Parser::GetImage (ZipParser.cpp:186-239 / RawParser.cpp:30-47 -> cv::imread / cv::imdecode, i.e. libpng + zlib):
+// a GPU box of this pool grants 16 host cores, and zlib's inflate is a serial byte recurrence (~2.3 ms per 1280x1024
+// frame and core), so the host cannot decode more than ~7 k frames/s however the rest is arranged.
+//
+// Three kernels per batch of encoded frames (the file bytes are uploaded as they are on disk):
+//   k_png_gather    one workgroup per frame: the IDAT chunks of the file (host-parsed offsets) -> one contiguous zlib stream
+//   k_png_inflate   ONE WAVE per frame (inflate is sequential in the stream, so the parallelism is frames x lanes):
+//                   every lane decodes one token SPECULATIVELY at bit offset ip + lane of the input (root-table look-up in
+//                   LDS, canonical compare for codes longer than the root); the real token starts are the chain
+//                   s, s + n(s), ... walked with v_readlane; an exclusive DPP scan of the output lengths places the
+//                   tokens; literals and short matches with old sources are written by their own lanes, dependent /
+//                   overlapping / long matches one after the other by the whole wave.  The 32 KiB history lives in LDS
+//                   (a ring), flushed to HBM in 16-byte pieces with the Adler-32 of the stream accumulated on the way
+//                   and checked against the trailer, as zlib does.
+//   k_png_unfilter  one wave per frame, lanes along x, rows in order (filter types None / Sub / Up in a few ops per
+//                   byte; Average and Paeth rows are a serial recurrence along x and take a lane-by-lane pass),
+//                   palette -> grey through the frame's 256-entry table, rows written coalesced into the frame slab.
+// Every access is bounds-checked against the sizes the caller states: the input is file content.  A frame the kernels
+// refuse (status != 0) is left to the caller, which decodes it on the host (the result is the same image or the same
+// failure: both follow RFC 1950/1951 and the PNG specification).
+#include "abub_dev.hpp"
+
+namespace {
+
+constexpr int PNG_WIN = 32768;   // deflate history
+constexpr int PNG_CAP = 1024;    // output bytes one iteration may produce (ring = history + this)
+constexpr int PNG_RING = PNG_WIN + PNG_CAP;
+constexpr int PNG_INDW = 512;    // input ring in dwords (2 KiB, refilled 1 KiB at a time, one refill prefetched in registers)
+constexpr int PNG_FLUSH = 2048;  // unflushed output that triggers a flush
+constexpr int LIT_ROOT = 10, DIST_ROOT = 9;
+constexpr int PNG_SHORT = 8;     // matches up to this length are copied by their own lane
+
+enum { K_LIT = 0, K_LEN = 1, K_EOB = 2, K_LONG = 3, K_BAD = 4 };
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ uint32_t below(uint64_t m) // set bits of m below this lane
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// cross-lane traffic through LDS inside one wave: the hardware keeps a wave's LDS operations in order, this keeps the
+// compiler from moving them across the hand-over
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+
+// inclusive wave scan (add) in 6 DPP steps (the sequence of LLVM's atomic optimizer for gfx9: row_shr 1,2,4,8, then
+// row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return rdl(wave_incl_scan(v), 63); }
+
+// canonical Huffman code of one alphabet (RFC 1951 3.2.2): uniform values, constant indices only (registers)
+struct Canon {
+    uint32_t first[16], count[16], offset[16];
+    uint32_t longer; // codes longer than the root table's index
+};
+
+// counts per length, Kraft check (zlib's inftrees.c rules: over-subscribed is an error; incomplete only for a lone
+// 1-bit distance code or an alphabet without any code), first codes and offsets.  `len` = this lane's symbols' lengths,
+// one per chunk of 64 symbols.  Returns false for a code zlib rejects.
+template <int CHUNKS>
+__device__ __forceinline__ bool canon_counts(const uint32_t (&len)[CHUNKS], Canon &C, int root, bool allow_single)
+{
+#pragma unroll
+    for (int l = 0; l < 16; ++l)
+        C.count[l] = 0;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c)
+#pragma unroll
+        for (int l = 1; l < 16; ++l)
+            C.count[l] += (uint32_t)__popcll(ballot(len[c] == (uint32_t)l));
+    int left = 1;
+    uint32_t mx = 0;
+    bool over = false;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) {
+        left = 2 * left - (int)C.count[l];
+        over |= left < 0;
+        if (C.count[l])
+            mx = l;
+    }
+    if (over)
+        return false;
+    if (left > 0 && mx != 0 && !(allow_single && mx == 1))
+        return false;
+    uint32_t code = 0, off = 0;
+    C.first[0] = C.offset[0] = 0;
+    C.longer = 0;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) {
+        code = (code + C.count[l - 1]) << 1;
+        C.first[l] = code;
+        C.offset[l] = off;
+        off += C.count[l];
+        if (l > root)
+            C.longer += C.count[l];
+    }
+    return true;
+}
+
+// symbols sorted by (length, symbol): sorted[offset[l] + rank among the symbols of length l] = symbol
+template <int CHUNKS>
+__device__ __forceinline__ void canon_sort(const uint32_t (&len)[CHUNKS], const Canon &C, uint16_t *sorted, int lane)
+{
+    uint32_t run[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l)
+        run[l] = C.offset[l];
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+        uint32_t pos = 0;
+#pragma unroll
+        for (int l = 1; l < 16; ++l) {
+            const uint64_t m = ballot(len[c] == (uint32_t)l);
+            if (len[c] == (uint32_t)l)
+                pos = run[l] + below(m);
+            run[l] += (uint32_t)__popcll(m);
+        }
+        if (len[c])
+            sorted[pos] = (uint16_t)(c * 64 + lane);
+    }
+}
+
+// canonical decode of the first bits of `rev` (the code bits MSB first in its low MAXL bits) for the lengths LO..HI:
+// position in `sorted` and length, or length 0
+template <int LO, int HI, int MAXL>
+__device__ __forceinline__ uint32_t canon_find(uint32_t rev, const Canon &C, uint32_t &pos)
+{
+    uint32_t found = 0;
+    pos = 0;
+#pragma unroll
+    for (int l = LO; l <= HI; ++l) {
+        const uint32_t idx = (rev >> (MAXL - l)) - C.first[l];
+        if (!found && idx < C.count[l]) {
+            found = l;
+            pos = C.offset[l] + idx;
+        }
+    }
+    return found;
+}
+
+__device__ __forceinline__ uint32_t lit_kind(uint32_t sym) { return sym < 256 ? K_LIT : sym == 256 ? K_EOB : sym < 286 ? K_LEN : K_BAD; }
+__device__ __forceinline__ uint32_t dist_kind(uint32_t sym) { return sym < 30 ? K_LIT : K_BAD; }
+// table entry: length (4 bits) | kind (3 bits) << 4 | symbol << 7
+__device__ __forceinline__ uint32_t entry_of(uint32_t l, uint32_t kind, uint32_t sym) { return l | (kind << 4) | (sym << 7); }
+
+// root table, one lane per entry: the entry's index bits are the next ROOT bits of the stream
+template <int ROOT, bool DIST>
+__device__ __forceinline__ void canon_table(const Canon &C, const uint16_t *sorted, uint16_t *tab, int lane)
+{
+    for (int e = lane; e < (1 << ROOT); e += 64) {
+        const uint32_t rev = __brev((uint32_t)e) >> (32 - ROOT);
+        uint32_t pos;
+        const uint32_t l = canon_find<1, ROOT, ROOT>(rev, C, pos);
+        uint32_t ent = entry_of(0, C.longer ? K_LONG : K_BAD, 0);
+        if (l) {
+            const uint32_t sym = sorted[pos];
+            ent = entry_of(l, DIST ? dist_kind(sym) : lit_kind(sym), sym);
+        }
+        tab[e] = (uint16_t)ent;
+    }
+}
+// codes longer than the root: canonical compare per length on the next 15 bits
+template <int ROOT, bool DIST>
+__device__ __forceinline__ uint32_t canon_slow(uint32_t bits, const Canon &C, const uint16_t *sorted)
+{
+    const uint32_t rev = __brev(bits) >> 17;
+    uint32_t pos;
+    const uint32_t l = canon_find<ROOT + 1, 15, 15>(rev, C, pos);
+    if (!l)
+        return entry_of(0, K_BAD, 0);
+    const uint32_t sym = sorted[pos];
+    return entry_of(l, DIST ? dist_kind(sym) : lit_kind(sym), sym);
+}
+
+__device__ const uint8_t png_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+struct InflateLds {
+    alignas(16) uint8_t win[PNG_RING];
+    alignas(16) uint32_t in[PNG_INDW];
+    uint16_t lit[1 << LIT_ROOT];
+    uint16_t dist[1 << DIST_ROOT];
+    uint16_t slit[288];
+    uint16_t sdist[32];
+    uint16_t scl[32];
+    uint8_t lens[320];
+    uint8_t cl[32];
+};
+
+// ---- gather: IDAT chunks -> one zlib stream per frame ------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_png_gather(const uint8_t *__restrict__ files, uint64_t files_bytes,
+                                                    const abub_png_frame *__restrict__ frames,
+                                                    const abub_png_seg *__restrict__ segs, uint32_t nsegs,
+                                                    uint8_t *__restrict__ zbuf, uint64_t zbuf_bytes,
+                                                    int32_t *__restrict__ status)
+{
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const abub_png_frame fr = frames[f];
+    const uint64_t zcap = (((uint64_t)fr.zlen + 15) & ~15ull) + 16;
+    bool bad = (fr.zoff & 15) || (uint64_t)fr.zoff + zcap > zbuf_bytes || (uint64_t)fr.seg_begin + fr.seg_count > nsegs;
+    uint64_t sum = 0;
+    if (!bad)
+        for (uint32_t s = 0; s < fr.seg_count; ++s) {
+            const abub_png_seg sg = segs[fr.seg_begin + s];
+            bad |= (uint64_t)sg.off + sg.len > files_bytes;
+            sum += sg.len;
+        }
+    bad |= sum != fr.zlen;
+    if (bad) { // (uniform: every thread read the same descriptor)
+        if (tid == 0)
+            status[f] = ABUB_PNG_E_DESC;
+        return;
+    }
+    uint8_t *z = zbuf + fr.zoff;
+    uint32_t run = 0;
+    for (uint32_t s = 0; s < fr.seg_count; ++s) {
+        const abub_png_seg sg = segs[fr.seg_begin + s];
+        const uint8_t *src = files + sg.off;
+        uint8_t *dst = z + run;
+        // head bytes up to a dword boundary of the destination, then dwords assembled from two aligned source dwords
+        const uint32_t head = min((uint32_t)((4 - ((uintptr_t)dst & 3)) & 3), sg.len);
+        if ((uint32_t)tid < head)
+            dst[tid] = src[tid];
+        const uint32_t nd = (sg.len - head) >> 2;
+        const uintptr_t sa0 = (uintptr_t)(src + head);
+        const uint32_t mis = (uint32_t)(sa0 & 3);
+        const uint32_t *sw = (const uint32_t *)(sa0 & ~(uintptr_t)3);
+        // (the second dword of the last pair may lie past the segment: inside `files` unless the segment ends it)
+        const bool tailSafe = (uint64_t)sg.off + sg.len + 8 <= files_bytes;
+        const uint32_t ndSafe = tailSafe ? nd : (nd > 2 ? nd - 2 : 0);
+        uint32_t *dw = (uint32_t *)(dst + head);
+        for (uint32_t k = tid; k < ndSafe; k += 256)
+            dw[k] = mis ? __builtin_amdgcn_alignbyte(sw[k + 1], sw[k], mis) : sw[k];
+        const uint32_t done = head + 4 * ndSafe;
+        for (uint32_t k = done + tid; k < sg.len; k += 256)
+            dst[k] = src[k];
+        run += sg.len;
+    }
+    for (uint32_t k = fr.zlen + tid; k < (uint32_t)zcap; k += 256)
+        z[k] = 0;
+    if (tid == 0)
+        status[f] = 0;
+}
+
+// ---- inflate: one wave per frame -----------------------------------------------------------------------------------
+struct InflateState {
+    const uint8_t *z;  // the frame's zlib stream
+    uint32_t zpad;     // its length rounded up to 16 (readable, zero-filled behind the stream)
+    uint32_t nbits;    // its length in bits
+    uint32_t in_hi;    // the input ring holds the stream's bytes [in_hi - 2048, in_hi)
+    uint4 pf;          // bytes [in_hi + 16 * lane, + 16), requested ahead
+    uint8_t *raw;      // output of this frame
+    uint32_t rawLen;   // exactly this many bytes are expected
+    uint32_t op, op_r; // output position, and the same modulo the ring
+    uint32_t fp;       // flushed up to here (multiple of 16)
+    uint32_t a1, a2;   // Adler-32 of the flushed bytes
+};
+
+__device__ __forceinline__ uint4 png_load16(const InflateState &S, uint32_t off)
+{
+    uint4 v = {0, 0, 0, 0};
+    if (off + 16 <= S.zpad)
+        v = *(const uint4 *)(S.z + off);
+    return v;
+}
+__device__ __forceinline__ void png_refill(InflateState &S, InflateLds &L, int lane)
+{
+    ((uint4 *)L.in)[((S.in_hi & (PNG_INDW * 4 - 1)) >> 4) + lane] = S.pf;
+    S.in_hi += 1024;
+    S.pf = png_load16(S, S.in_hi + 16 * lane);
+    wave_sync();
+}
+// (re)start the input ring at bit position ip
+__device__ __forceinline__ void png_in_start(InflateState &S, InflateLds &L, uint32_t ip, int lane)
+{
+    S.in_hi = (ip >> 3) & ~1023u;
+    S.pf = png_load16(S, S.in_hi + 16 * lane);
+    png_refill(S, L, lane);
+}
+// the ring covers every dword a window read at bit positions ip .. ip + 63 touches (and 32-bit peeks at ip)
+__device__ __forceinline__ void png_ensure(InflateState &S, InflateLds &L, uint32_t ip, int lane)
+{
+    const uint32_t need = ((ip + 127) >> 5) * 4 + 12;
+    while (need > S.in_hi)
+        png_refill(S, L, lane);
+}
+// 32 bits of the stream at bit position pos (any lane-specific pos inside the ensured range)
+__device__ __forceinline__ uint32_t png_bits32(const InflateLds &L, uint32_t pos)
+{
+    const uint32_t w = pos >> 5;
+    return __builtin_amdgcn_alignbit(L.in[(w + 1) & (PNG_INDW - 1)], L.in[w & (PNG_INDW - 1)], pos & 31);
+}
+__device__ __forceinline__ uint32_t ring_wrap(uint32_t i) { return i >= (uint32_t)PNG_RING ? i - PNG_RING : i; }
+
+// ring -> HBM for the bytes [fp, upto), Adler-32 on the way; upto is a multiple of 16 unless `last`
+__device__ __forceinline__ void png_flush(InflateState &S, InflateLds &L, uint32_t upto, bool last, int lane)
+{
+    const uint32_t n = upto - S.fp;
+    if (!n)
+        return;
+    uint32_t s1 = 0, s2 = 0; // this lane's sum of bytes and sum of (n - k) * byte[k], k = index inside the piece
+    const uint32_t fr = S.fp % PNG_RING;
+    for (uint32_t k0 = 16 * lane; k0 + 16 <= n; k0 += 1024) {
+        const uint4 v = *(const uint4 *)&L.win[ring_wrap(fr + k0)];
+        *(uint4 *)(S.raw + S.fp + k0) = v;
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t byte = (d[q] >> (8 * b)) & 255;
+                s1 += byte;
+                s2 += (n - (k0 + 4 * q + b)) * byte;
+            }
+    }
+    if (last) {
+        const uint32_t t0 = n & ~15u;
+        if (t0 + lane < n) {
+            const uint32_t byte = L.win[ring_wrap(fr + t0 + lane)];
+            S.raw[S.fp + t0 + lane] = (uint8_t)byte;
+            s1 += byte;
+            s2 += (n - (t0 + lane)) * byte;
+        }
+    }
+    // (a lane sees at most ceil(n / 1024) * 16 + 1 bytes of a piece of < 8 KiB: both sums stay far below 2^32)
+    const uint32_t S1 = wave_sum(s1 % 65521u), S2 = wave_sum(s2 % 65521u);
+    S.a2 = (S.a2 + ((n % 65521u) * S.a1) % 65521u + S2) % 65521u;
+    S.a1 = (S.a1 + S1) % 65521u;
+    S.fp = upto;
+}
+__device__ __forceinline__ void png_advance(InflateState &S, InflateLds &L, uint32_t total, int lane)
+{
+    S.op += total;
+    S.op_r = ring_wrap(S.op_r + total);
+    if (S.op - S.fp >= (uint32_t)PNG_FLUSH) {
+        wave_sync();
+        png_flush(S, L, S.op & ~15u, false, lane);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_png_inflate(const uint8_t *__restrict__ zbuf, const abub_png_frame *__restrict__ frames,
+                                                    uint32_t rawLen, uint64_t rawStride, uint8_t *__restrict__ rawbuf,
+                                                    int32_t *__restrict__ status)
+{
+    __shared__ InflateLds L;
+    const int f = blockIdx.x, lane = threadIdx.x;
+    if (status[f] != 0) // (refused by the gather kernel; uniform)
+        return;
+    const abub_png_frame fr = frames[f];
+    InflateState S;
+    S.z = zbuf + fr.zoff;
+    S.zpad = (fr.zlen + 15) & ~15u;
+    S.nbits = fr.zlen * 8;
+    S.raw = rawbuf + (uint64_t)f * rawStride;
+    S.rawLen = rawLen;
+    S.op = S.op_r = S.fp = 0;
+    S.a1 = 1;
+    S.a2 = 0;
+    int err = 0;
+    uint32_t ip = 16;
+    png_in_start(S, L, 0, lane);
+    png_ensure(S, L, 0, lane);
+    if (fr.zlen < 6 || fr.zlen >= (1u << 28))
+        err = ABUB_PNG_E_TRUNCATED;
+    else {
+        const uint32_t h = rfl(png_bits32(L, 0));
+        const uint32_t cmf = h & 255, flg = (h >> 8) & 255;
+        if ((cmf & 15) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 || (flg & 0x20))
+            err = ABUB_PNG_E_HEADER;
+    }
+    bool final = false;
+    while (!err && !final) {
+        png_ensure(S, L, ip, lane);
+        if (ip + 3 > S.nbits) {
+            err = ABUB_PNG_E_TRUNCATED;
+            break;
+        }
+        uint32_t hv = rfl(png_bits32(L, ip));
+        final = hv & 1;
+        const uint32_t btype = (hv >> 1) & 3;
+        ip += 3;
+        if (btype == 3) {
+            err = ABUB_PNG_E_BLOCKTYPE;
+            break;
+        }
+        if (btype == 0) { // stored: straight from the stream into the ring
+            ip = (ip + 7) & ~7u;
+            png_ensure(S, L, ip, lane);
+            if (ip + 32 > S.nbits) {
+                err = ABUB_PNG_E_TRUNCATED;
+                break;
+            }
+            hv = rfl(png_bits32(L, ip));
+            const uint32_t len = hv & 0xffff;
+            if ((len ^ (hv >> 16)) != 0xffff) {
+                err = ABUB_PNG_E_STORED;
+                break;
+            }
+            ip += 32;
+            uint32_t bp = ip >> 3;
+            if ((uint64_t)bp + len > fr.zlen) {
+                err = ABUB_PNG_E_TRUNCATED;
+                break;
+            }
+            if (S.op + len > S.rawLen) {
+                err = ABUB_PNG_E_TOOMUCH;
+                break;
+            }
+            for (uint32_t rem = len; rem;) {
+                const uint32_t chunk = min(rem, (uint32_t)PNG_CAP);
+                for (uint32_t k = lane; k < chunk; k += 64)
+                    L.win[ring_wrap(S.op_r + k)] = S.z[bp + k];
+                bp += chunk;
+                rem -= chunk;
+                png_advance(S, L, chunk, lane);
+            }
+            ip = bp * 8;
+            png_in_start(S, L, ip, lane);
+            continue;
+        }
+        // ---- code lengths of the block -> LDS lens[0 .. 288) literal/length, lens[288 .. 320) distance ----
+        uint32_t hlit = 288, hdist = 32;
+        if (btype == 1) {
+            for (int s = lane; s < 320; s += 64)
+                L.lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
+        } else {
+            if (ip + 14 > S.nbits) {
+                err = ABUB_PNG_E_TRUNCATED;
+                break;
+            }
+            hv = rfl(png_bits32(L, ip));
+            hlit = (hv & 31) + 257;
+            hdist = ((hv >> 5) & 31) + 1;
+            const uint32_t hclen = ((hv >> 10) & 15) + 4;
+            ip += 14;
+            if (hlit > 286 || hdist > 30) {
+                err = ABUB_PNG_E_SYMBOLS;
+                break;
+            }
+            png_ensure(S, L, ip, lane);
+            if (lane < 32)
+                L.cl[lane] = 0;
+            wave_sync();
+            if ((uint32_t)lane < hclen)
+                L.cl[png_cl_order[lane]] = (uint8_t)(png_bits32(L, ip + 3 * lane) & 7);
+            wave_sync();
+            ip += 3 * hclen;
+            uint32_t cll[1] = {lane < 19 ? (uint32_t)L.cl[lane] : 0u};
+            Canon CC;
+            if (!canon_counts<1>(cll, CC, 7, false) || CC.count[1] + CC.count[2] + CC.count[3] + CC.count[4] + CC.count[5] + CC.count[6] + CC.count[7] == 0) {
+                err = ABUB_PNG_E_CODES;
+                break;
+            }
+            canon_sort<1>(cll, CC, L.scl, lane);
+            wave_sync();
+            // the code-length code's 128-entry table lives in two registers per lane (entry e: lane e & 63, register e >> 6)
+            uint32_t clt[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const uint32_t rev = __brev((uint32_t)(lane + 64 * q)) >> 25;
+                uint32_t pos;
+                const uint32_t l = canon_find<1, 7, 7>(rev, CC, pos);
+                clt[q] = l ? (l | ((uint32_t)L.scl[pos] << 4)) : 0u;
+            }
+            const uint32_t total = hlit + hdist;
+            uint32_t n = 0, prev = 0;
+            while (n < total) {
+                png_ensure(S, L, ip, lane);
+                uint32_t v = rfl(png_bits32(L, ip));
+                const uint32_t idx = v & 127;
+                const uint32_t ent = idx < 64 ? rdl(clt[0], idx) : rdl(clt[1], idx - 64);
+                const uint32_t l = ent & 15, sym = ent >> 4;
+                if (!l) {
+                    err = ABUB_PNG_E_CODES;
+                    break;
+                }
+                v >>= l;
+                ip += l;
+                uint32_t rep = 1, val = sym;
+                if (sym == 16) {
+                    if (!n) {
+                        err = ABUB_PNG_E_CODES;
+                        break;
+                    }
+                    rep = 3 + (v & 3);
+                    val = prev;
+                    ip += 2;
+                } else if (sym == 17) {
+                    rep = 3 + (v & 7);
+                    val = 0;
+                    ip += 3;
+                } else if (sym == 18) {
+                    rep = 11 + (v & 127);
+                    val = 0;
+                    ip += 7;
+                }
+                if (n + rep > total) {
+                    err = ABUB_PNG_E_CODES;
+                    break;
+                }
+                for (uint32_t k = lane; k < rep; k += 64) { // literal/length lengths at lens[0 ..), distance lengths at lens[288 ..)
+                    const uint32_t s = n + k;
+                    L.lens[s < hlit ? s : 288 + (s - hlit)] = (uint8_t)val;
+                }
+                prev = val;
+                n += rep;
+            }
+            if (err)
+                break;
+            if (ip > S.nbits) {
+                err = ABUB_PNG_E_TRUNCATED;
+                break;
+            }
+            wave_sync();
+        }
+        wave_sync();
+        // ---- tables ----
+        Canon CL, CD;
+        {
+            uint32_t ll[5];
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                const uint32_t s = c * 64 + lane;
+                ll[c] = s < hlit ? (uint32_t)L.lens[s] : 0u;
+            }
+            const uint32_t eob = rdl(ll[4], 0); // symbol 256
+            if (!canon_counts<5>(ll, CL, LIT_ROOT, true)) {
+                err = ABUB_PNG_E_CODES;
+                break;
+            }
+            if (!eob) {
+                err = ABUB_PNG_E_NOEOB;
+                break;
+            }
+            canon_sort<5>(ll, CL, L.slit, lane);
+            uint32_t dl[1] = {(uint32_t)lane < hdist ? (uint32_t)L.lens[288 + lane] : 0u};
+            if (!canon_counts<1>(dl, CD, DIST_ROOT, true)) {
+                err = ABUB_PNG_E_CODES;
+                break;
+            }
+            canon_sort<1>(dl, CD, L.sdist, lane);
+            wave_sync();
+            canon_table<LIT_ROOT, false>(CL, L.slit, L.lit, lane);
+            canon_table<DIST_ROOT, true>(CD, L.sdist, L.dist, lane);
+            wave_sync();
+        }
+        // ---- tokens ----
+        uint32_t s = 0; // first real token start inside the window
+        for (;;) {
+            png_ensure(S, L, ip, lane);
+            if (ip > S.nbits) {
+                err = ABUB_PNG_E_TRUNCATED;
+                break;
+            }
+            const uint32_t pos = ip + lane, w = pos >> 5, sh = pos & 31;
+            const uint32_t d0 = L.in[w & (PNG_INDW - 1)], d1 = L.in[(w + 1) & (PNG_INDW - 1)], d2 = L.in[(w + 2) & (PNG_INDW - 1)];
+            const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+            const uint64_t W = ((uint64_t)hi << 32) | lo;
+            uint32_t e = L.lit[lo & ((1u << LIT_ROOT) - 1)];
+            if (ballot(((e >> 4) & 7) == K_LONG)) {
+                if (((e >> 4) & 7) == K_LONG)
+                    e = canon_slow<LIT_ROOT, false>(lo, CL, L.slit);
+            }
+            uint32_t kind = (e >> 4) & 7, nb = e & 15;
+            const uint32_t sym = e >> 7;
+            uint32_t olen = kind == K_LIT ? 1u : 0u, dist = 0;
+            if (ballot(kind == K_LEN)) {
+                const uint32_t i = kind == K_LEN ? sym - 257 : 0u;
+                const uint32_t eb = (i < 8 || i == 28) ? 0u : (i - 4) >> 2;
+                const uint32_t base = i < 8 ? 3 + i : i == 28 ? 258u : 3 + ((4 + (i & 3)) << eb);
+                const uint32_t len = base + ((uint32_t)(W >> nb) & ((1u << eb) - 1));
+                const uint32_t nb2 = nb + eb;
+                const uint32_t w2 = (uint32_t)(W >> nb2);
+                uint32_t de = L.dist[w2 & ((1u << DIST_ROOT) - 1)];
+                if (ballot(kind == K_LEN && ((de >> 4) & 7) == K_LONG)) {
+                    if (kind == K_LEN && ((de >> 4) & 7) == K_LONG)
+                        de = canon_slow<DIST_ROOT, true>(w2, CD, L.sdist);
+                }
+                const uint32_t dk = (de >> 4) & 7, dsym = de >> 7, dnb = de & 15;
+                const uint32_t deb = dsym < 4 ? 0u : (dsym - 2) >> 1;
+                const uint32_t dbase = dsym < 4 ? 1 + dsym : 1 + ((2 + (dsym & 1)) << deb);
+                const uint32_t nb3 = nb2 + dnb;
+                const uint32_t dd = dbase + ((uint32_t)(W >> nb3) & ((1u << deb) - 1));
+                if (kind == K_LEN) {
+                    olen = len;
+                    dist = dd;
+                    nb = nb3 + deb;
+                    if (dk != K_LIT)
+                        kind = K_BAD;
+                }
+            }
+            // ---- the chain of real tokens: s, s + n(s), ... ----
+            const uint32_t packed = nb | (kind << 6) | (olen << 9);
+            uint64_t valid = 0;
+            uint32_t p = s, total = 0;
+            bool eob = false, capped = false;
+            while (p < 64) {
+                const uint32_t t = rdl(packed, p);
+                const uint32_t k = (t >> 6) & 7, ol = t >> 9;
+                if (k == K_BAD) {
+                    err = ABUB_PNG_E_CODE;
+                    break;
+                }
+                if (total + ol > (uint32_t)PNG_CAP) {
+                    capped = true;
+                    break;
+                }
+                valid |= 1ull << p;
+                total += ol;
+                p += t & 63;
+                if (k == K_EOB) {
+                    eob = true;
+                    break;
+                }
+            }
+            if (err)
+                break;
+            if (eob || capped) {
+                ip += p;
+                s = 0;
+            } else {
+                ip += 64;
+                s = p - 64;
+            }
+            if (ip > S.nbits) {
+                err = ABUB_PNG_E_TRUNCATED;
+                break;
+            }
+            if (S.op + total > S.rawLen) {
+                err = ABUB_PNG_E_TOOMUCH;
+                break;
+            }
+            const bool mine = (valid >> lane) & 1;
+            const bool isMatch = mine && kind == K_LEN;
+            const uint64_t mm = ballot(isMatch);
+            uint32_t off;
+            if (!mm)
+                off = below(valid); // literals only (an end-of-block token is the chain's last)
+            else {
+                const uint32_t ol = mine ? olen : 0u;
+                off = wave_incl_scan(ol) - ol;
+            }
+            if (mine && kind == K_LIT)
+                L.win[ring_wrap(S.op_r + off)] = (uint8_t)sym;
+            if (mm) {
+                if (ballot(isMatch && dist > S.op + off)) {
+                    err = ABUB_PNG_E_DISTANCE;
+                    break;
+                }
+                const uint32_t m0 = rdl(off, (uint32_t)__builtin_ctzll(mm)); // output offset of the iteration's first match
+                // a match whose source ends behind m0 may read what an earlier match of this iteration writes
+                const bool dep = isMatch && (int)(off + olen) - (int)dist > (int)m0;
+                const bool own = isMatch && !dep && olen <= (uint32_t)PNG_SHORT;
+                wave_sync();
+                if (ballot(own)) {
+                    uint32_t sidx = S.op_r + off + PNG_RING - dist; // < 2 * RING + CAP
+                    sidx = ring_wrap(ring_wrap(sidx));
+                    const uint32_t didx = ring_wrap(S.op_r + off);
+                    uint32_t b[PNG_SHORT];
+#pragma unroll
+                    for (int k = 0; k < PNG_SHORT; ++k)
+                        b[k] = (own && (uint32_t)k < olen) ? (uint32_t)L.win[ring_wrap(sidx + k)] : 0u;
+#pragma unroll
+                    for (int k = 0; k < PNG_SHORT; ++k)
+                        if (own && (uint32_t)k < olen)
+                            L.win[ring_wrap(didx + k)] = (uint8_t)b[k];
+                }
+                uint64_t rest = ballot(isMatch && !own);
+                while (rest) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(rest);
+                    rest &= rest - 1;
+                    const uint32_t o = rdl(off, j), len = rdl(olen, j), d = rdl(dist, j);
+                    wave_sync();
+                    const uint32_t dst0 = ring_wrap(S.op_r + o);
+                    const uint32_t src0 = ring_wrap(ring_wrap(S.op_r + o + PNG_RING - d));
+                    const float rcp = 1.0f / (float)d;
+                    for (uint32_t k0 = 0; k0 < len; k0 += 64) {
+                        const uint32_t k = k0 + lane;
+                        uint32_t r = k;
+                        if (d < len) { // overlapping: byte k repeats the pattern of d bytes
+                            uint32_t q = (uint32_t)((float)k * rcp);
+                            int rr = (int)k - (int)(q * d);
+                            if (rr < 0)
+                                rr += (int)d;
+                            if (rr >= (int)d)
+                                rr -= (int)d;
+                            r = (uint32_t)rr;
+                        }
+                        if (k < len) {
+                            const uint8_t byte = L.win[ring_wrap(src0 + r)];
+                            L.win[ring_wrap(dst0 + k)] = byte;
+                        }
+                    }
+                }
+            }
+            png_advance(S, L, total, lane);
+            if (eob)
+                break;
+        }
+    }
+    if (!err) {
+        wave_sync();
+        png_flush(S, L, S.op, true, lane);
+        if (S.op != S.rawLen)
+            err = ABUB_PNG_E_TOOLITTLE;
+        else {
+            ip = (ip + 7) & ~7u;
+            if (ip + 32 > S.nbits)
+                err = ABUB_PNG_E_TRUNCATED;
+            else {
+                png_ensure(S, L, ip, lane);
+                const uint32_t t = rfl(png_bits32(L, ip));
+                if (__builtin_bswap32(t) != ((S.a2 << 16) | S.a1))
+                    err = ABUB_PNG_E_ADLER;
+            }
+        }
+    }
+    if (lane == 0)
+        status[f] = err;
+}
+
+// ---- unfilter: one wave per frame, lanes along x, rows in order ----------------------------------------------------
+__device__ __forceinline__ uint32_t add4(uint32_t a, uint32_t b) // four byte-wise sums modulo 256
+{
+    return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);
+}
+__device__ __forceinline__ int paeth(int a, int b, int c)
+{
+    const int pa = abs(b - c), pb = abs(a - c), pc = abs(a + b - 2 * c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+template <int NDW>
+__global__ __launch_bounds__(64) void k_png_unfilter(const uint8_t *__restrict__ rawbuf, uint64_t rawStride,
+                                                     const abub_png_frame *__restrict__ frames, const uint8_t *__restrict__ luts,
+                                                     uint32_t nluts, int W, int H, uint8_t *__restrict__ out, uint64_t out_bytes,
+                                                     int32_t *__restrict__ status)
+{
+    __shared__ uint8_t lut[256];
+    const int f = blockIdx.x, lane = threadIdx.x;
+    if (status[f] != 0)
+        return;
+    const abub_png_frame fr = frames[f];
+    const bool pal = fr.lut != 0xffffffffu;
+    if (fr.dst + (uint64_t)W * H > out_bytes || (fr.dst & 3) || (pal && fr.lut >= nluts)) {
+        if (lane == 0)
+            status[f] = ABUB_PNG_E_DESC;
+        return;
+    }
+    if (pal) {
+        for (int i = lane; i < 256; i += 64)
+            lut[i] = luts[(uint64_t)fr.lut * 256 + i];
+        wave_sync();
+    }
+    const uint8_t *raw = rawbuf + (uint64_t)f * rawStride; // 16-byte aligned; row y at y * (W + 1), its filter type first
+    uint8_t *dst = out + fr.dst;
+    const int x0 = lane * 4 * NDW;            // this lane's bytes of a row: [x0, x0 + 4 * NDW)
+    const int nmine = min(max(W - x0, 0), 4 * NDW); // (a multiple of 4: W is)
+    uint32_t prev[NDW];
+#pragma unroll
+    for (int q = 0; q < NDW; ++q)
+        prev[q] = 0;
+    // row loads run two rows ahead of the arithmetic
+    auto load_row = [&](int y, uint32_t (&d)[NDW + 1], uint32_t &ft) {
+        const uint64_t rb = (uint64_t)y * (W + 1);
+        ft = raw[rb];
+        const uint64_t a = rb + 1 + x0;
+        const uint32_t *p = (const uint32_t *)(raw + (a & ~3ull));
+#pragma unroll
+        for (int q = 0; q <= NDW; ++q) // (rawStride leaves 8 readable bytes behind the last row)
+            d[q] = (nmine > 0 && 4 * q < nmine + 4) ? p[q] : 0u;
+    };
+    auto row_words = [&](int y, const uint32_t (&d)[NDW + 1], uint32_t (&r)[NDW]) {
+        const uint32_t mis = (uint32_t)(((uint64_t)y * (W + 1) + 1 + x0) & 3);
+#pragma unroll
+        for (int q = 0; q < NDW; ++q)
+            r[q] = 4 * q < nmine ? (mis ? __builtin_amdgcn_alignbyte(d[q + 1], d[q], mis) : d[q]) : 0u;
+    };
+    uint32_t dA[NDW + 1], dB[NDW + 1], ftA = 0, ftB = 0;
+    if (H > 0)
+        load_row(0, dA, ftA);
+    if (H > 1)
+        load_row(1, dB, ftB);
+    int bad = 0;
+    for (int y = 0; y < H; ++y) {
+        uint32_t r[NDW];
+        row_words(y, dA, r);
+        const uint32_t ft = rfl(ftA);
+#pragma unroll
+        for (int q = 0; q <= NDW; ++q)
+            dA[q] = dB[q];
+        ftA = ftB;
+        if (y + 2 < H)
+            load_row(y + 2, dB, ftB);
+        uint32_t o[NDW];
+        if (ft == 0) {
+#pragma unroll
+            for (int q = 0; q < NDW; ++q)
+                o[q] = r[q];
+        } else if (ft == 2) {
+#pragma unroll
+            for (int q = 0; q < NDW; ++q)
+                o[q] = add4(r[q], prev[q]);
+        } else if (ft == 1) {
+            // prefix sums modulo 256 along the row: inside the lane, then the lanes' totals
+            uint32_t acc = 0;
+#pragma unroll
+            for (int q = 0; q < NDW; ++q) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    acc = (acc + ((r[q] >> (8 * b)) & 255)) & 255;
+                    w |= acc << (8 * b);
+                }
+                o[q] = w;
+            }
+            const uint32_t carry = (wave_incl_scan(acc) - acc) & 255;
+            const uint32_t c4 = carry * 0x01010101u;
+#pragma unroll
+            for (int q = 0; q < NDW; ++q)
+                o[q] = add4(o[q], c4);
+        } else if (ft == 3 || ft == 4) {
+            // serial along x: every lane works its bytes from the left neighbour's last output; after round i the lanes
+            // 0 .. i hold their final bytes (lane i's carry-in was final in round i)
+            uint32_t left = 0; // the last output byte of the lane to the left
+            for (int round = 0; round < 64; ++round) {
+                int a = (int)left;
+                // up-left of my first byte (the DPP move runs with every lane active: a disabled source lane would not be read;
+                // lane 0 has no source and keeps the 0)
+                int c = (int)((uint32_t)__builtin_amdgcn_update_dpp(0u, prev[NDW - 1], 0x138, 0xf, 0xf, false) >> 24); // (the builtin returns int)
+#pragma unroll
+                for (int q = 0; q < NDW; ++q) {
+                    uint32_t w = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int up = (int)((prev[q] >> (8 * b)) & 255);
+                        const int x = (int)((r[q] >> (8 * b)) & 255);
+                        const int pred = ft == 3 ? ((a + up) >> 1) : paeth(a, up, c);
+                        a = (x + pred) & 255;
+                        c = up;
+                        w |= (uint32_t)a << (8 * b);
+                    }
+                    o[q] = w;
+                }
+                left = __builtin_amdgcn_update_dpp(0u, (uint32_t)a, 0x138, 0xf, 0xf, false); // wave_shr:1 (lane 0 keeps 0)
+                if ((round + 1) * 4 * NDW >= W) // the lanes that hold pixels are final
+                    break;
+            }
+        } else {
+            bad = 1;
+            break;
+        }
+#pragma unroll
+        for (int q = 0; q < NDW; ++q)
+            prev[q] = o[q];
+        uint32_t *drow = (uint32_t *)(dst + (uint64_t)y * W + x0);
+#pragma unroll
+        for (int q = 0; q < NDW; ++q) {
+            uint32_t v = o[q];
+            if (pal) {
+                v = (uint32_t)lut[v & 255] | ((uint32_t)lut[(v >> 8) & 255] << 8) | ((uint32_t)lut[(v >> 16) & 255] << 16) |
+                    ((uint32_t)lut[v >> 24] << 24);
+            }
+            if (4 * q < nmine)
+                drow[q] = v;
+        }
+    }
+    if (bad && lane == 0)
+        status[f] = ABUB_PNG_E_FILTER;
+}
+
+} // namespace
+
+extern "C" size_t abub_png_raw_stride(int W, int H)
+{
+    if (W <= 0 || H <= 0)
+        return 0;
+    return (((size_t)H * ((size_t)W + 1) + 15) & ~(size_t)15) + 16;
+}
+
+extern "C" int abub_png_decode_dev(const uint8_t *files, size_t files_bytes, const abub_png_frame *frames, int nframes,
+                                   const abub_png_seg *segs, int nsegs, const uint8_t *luts, int nluts, int W, int H,
+                                   uint8_t *zbuf, size_t zbuf_bytes, uint8_t *rawbuf, size_t rawbuf_bytes, uint8_t *out,
+                                   size_t out_bytes, int32_t *status, void *stream)
+{
+    if (nframes == 0)
+        return ABUB_OK;
+    if (!files || !frames || !zbuf || !rawbuf || !out || !status || nframes < 0 || nsegs < 0 || nluts < 0 || (nsegs && !segs) ||
+        (nluts && !luts))
+        return set_err(ABUB_E_INVALID, "abub_png_decode_dev: null pointer or negative count");
+    if (W < 4 || (W & 3) || W > 2048 || H < 1 || (size_t)H * ((size_t)W + 1) >= ((size_t)1 << 31))
+        return set_err(ABUB_E_INVALID, "abub_png_decode_dev: width must be a multiple of 4 in [4, 2048]");
+    if (((uintptr_t)files & 3) || ((uintptr_t)zbuf & 15) || ((uintptr_t)rawbuf & 15) || ((uintptr_t)out & 3))
+        return set_err(ABUB_E_INVALID, "abub_png_decode_dev: files / out 4-byte, zbuf / rawbuf 16-byte aligned");
+    const size_t stride = abub_png_raw_stride(W, H);
+    if ((size_t)nframes * stride > rawbuf_bytes)
+        return set_err(ABUB_E_INVALID, "abub_png_decode_dev: rawbuf smaller than nframes * abub_png_raw_stride(W, H)");
+    hipStream_t st = (hipStream_t)stream;
+    k_png_gather<<<nframes, 256, 0, st>>>(files, (uint64_t)files_bytes, frames, segs, (uint32_t)nsegs, zbuf, (uint64_t)zbuf_bytes, status);
+    k_png_inflate<<<nframes, 64, 0, st>>>(zbuf, frames, (uint32_t)((size_t)H * ((size_t)W + 1)), (uint64_t)stride, rawbuf, status);
+    const int ndw = (W + 255) / 256;
+#define UNF(N)                                                                                                             \
+    k_png_unfilter<N><<<nframes, 64, 0, st>>>(rawbuf, (uint64_t)stride, frames, luts, (uint32_t)nluts, W, H, out,         \
+                                              (uint64_t)out_bytes, status)
+    switch (ndw) {
+    case 1: UNF(1); break;
+    case 2: UNF(2); break;
+    case 3: UNF(3); break;
+    case 4: UNF(4); break;
+    case 5: UNF(5); break;
+    case 6: UNF(6); break;
+    case 7: UNF(7); break;
+    default: UNF(8); break;
+    }
+#undef UNF
+    HIPCHK(hipGetLastError());
+    return ABUB_OK;
+}

@@ -164,3 +164,83 @@ def fg_compact(img, thr, cap):
     _lib.check(_lib.lib().abub_fg_compact_dev(_ptr(img), n, W, H, _ptr(thr), _ptr(idx), cap, _ptr(cnt),
                                               _stream()), "abub_fg_compact_dev")
     return idx, cnt
+
+
+# ---- PNG frames decoded on the GPU (abub_png_decode_dev) --------------------------------------------------------
+def png_parse(data, W, H):
+    """What the host does per file before the upload: walk the chunks of a PNG, -> (idat segments [(offset, length)],
+    palette->grey table (bytes, 256) or None) for an 8-bit grey / 8-bit palette image of W x H without interlace, or None
+    for anything the GPU path does not take (the caller decodes such a file on the host)."""
+    import struct
+    if len(data) < 33 or data[:8] != b"\x89PNG\r\n\x1a\n":
+        return None
+    o, segs, pal, hdr, end = 8, [], None, None, False
+    while not end and o + 12 <= len(data):
+        ln, = struct.unpack(">I", data[o:o + 4])
+        typ = data[o + 4:o + 8]
+        if o + 12 + ln > len(data):
+            return None
+        if typ == b"IHDR" and ln >= 13:
+            hdr = struct.unpack(">IIBBBBB", data[o + 8:o + 21])
+        elif typ == b"PLTE":
+            pal = data[o + 8:o + 8 + ln]
+        elif typ == b"IDAT":
+            segs.append((o + 8, ln))
+        elif typ == b"IEND":
+            end = True
+        o += 12 + ln
+    if hdr is None or not segs or hdr[0] != W or hdr[1] != H or hdr[2] != 8 or hdr[3] not in (0, 3) or hdr[6] != 0:
+        return None
+    lut = None
+    if hdr[3] == 3:
+        n = min(len(pal or b"") // 3, 256)
+        lut = bytes(((pal[3 * i] * 9797 + pal[3 * i + 1] * 19234 + pal[3 * i + 2] * 3737 + 16384) >> 15) & 255 if i < n else 0
+                    for i in range(256))
+    return segs, lut
+
+
+def png_decode(files, W, H, device="cuda:0"):
+    """files: list of bytes objects (PNG files) -> (frames u8 [n, H, W] on the device, status i32 [n] on the host).  A file
+    png_parse() refuses gets status -1 and a frame left untouched (zeros)."""
+    import numpy as np
+    n = len(files)
+    frames_np = np.zeros((max(n, 1), 8), dtype=np.uint32)
+    segs, luts, blob, zoff = [], [], bytearray(), 0
+    status_pre = np.zeros(n, dtype=np.int32)
+    P = W * H
+    for i, data in enumerate(files):
+        parsed = png_parse(data, W, H)
+        base = len(blob)
+        if parsed is None:
+            status_pre[i] = -1
+            frames_np[i] = (len(segs), 0, zoff, 0, 0xFFFFFFFF, 0, (i * P) & 0xFFFFFFFF, (i * P) >> 32)
+            zoff += 16
+            continue
+        sg, lut = parsed
+        zlen = sum(l for _, l in sg)
+        li = 0xFFFFFFFF
+        if lut is not None:
+            li = len(luts)
+            luts.append(lut)
+        frames_np[i] = (len(segs), len(sg), zoff, zlen, li, 0, (i * P) & 0xFFFFFFFF, (i * P) >> 32)
+        segs += [(base + o, l) for o, l in sg]
+        blob += data
+        blob += b"\0" * ((-len(blob)) % 4)
+        zoff += ((zlen + 15) & ~15) + 16
+    blob += b"\0" * 8
+    dev = torch.device(device)
+    d_files = torch.frombuffer(bytes(blob), dtype=torch.uint8).to(dev)
+    d_frames = torch.from_numpy(frames_np.view(np.int32).copy()).to(dev)
+    d_segs = torch.tensor(segs if segs else [(0, 0)], dtype=torch.int64).to(torch.int32).to(dev) if True else None
+    d_luts = torch.frombuffer(b"".join(luts) if luts else bytes(256), dtype=torch.uint8).to(dev)
+    stride = int(_lib.lib().abub_png_raw_stride(W, H))
+    d_z = torch.empty((max(zoff, 16),), dtype=torch.uint8, device=dev)
+    d_raw = torch.empty((max(n, 1) * stride,), dtype=torch.uint8, device=dev)
+    out = torch.zeros((max(n, 1), H, W), dtype=torch.uint8, device=dev)
+    status = torch.full((max(n, 1),), 99, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().abub_png_decode_dev(_ptr(d_files), d_files.numel(), _ptr(d_frames), n, _ptr(d_segs), len(segs),
+                                              _ptr(d_luts), len(luts), W, H, _ptr(d_z), d_z.numel(), _ptr(d_raw), d_raw.numel(),
+                                              _ptr(out), out.numel(), _ptr(status), _stream()), "abub_png_decode_dev")
+    st = status.cpu().numpy()[:n].copy()
+    st[status_pre != 0] = -1
+    return out[:n], st

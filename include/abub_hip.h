@@ -256,6 +256,53 @@ int abub_ctx_set_image(abub_ctx *ctx, const uint8_t *img);
 /* Copy the current image to the host (debug write-out / overflow fallback). */
 int abub_ctx_fetch_image(abub_ctx *ctx, uint8_t *out);
 
+/* ---- PNG frames decoded on the GPU (abub_png.hip) -------------------------------------------------------------
+ * Replaces, for batches of frames, the host decode behind Parser::GetImage (ZipParser.cpp:186-239, RawParser.cpp:30-47:
+ * cv::imdecode / cv::imread = libpng + zlib).  The caller uploads the FILES as they are on disk and describes each
+ * frame: where its IDAT chunks lie, where its zlib stream may be assembled, where the decoded frame goes.  Handles
+ * 8-bit grey and 8-bit palette images without interlace, any filter type, any deflate block type; a frame the kernels
+ * refuse gets a positive status (below) and is left as it is -- the caller decodes such a frame on the host.
+ * All pointers are device pointers; nothing here reads host memory. */
+typedef struct abub_png_seg {
+    uint32_t off; /* byte offset of an IDAT chunk's DATA in `files` */
+    uint32_t len; /* its length */
+} abub_png_seg;
+typedef struct abub_png_frame {
+    uint32_t seg_begin; /* first entry of this frame in segs[] */
+    uint32_t seg_count; /* its IDAT chunks, in file order */
+    uint32_t zoff;      /* where the frame's zlib stream is assembled in `zbuf`: a multiple of 16, with room for zlen
+                           rounded up to 16, plus 16 */
+    uint32_t zlen;      /* sum of the segment lengths */
+    uint32_t lut;       /* palette images: index of the frame's 256-byte palette-index -> grey table in `luts`;
+                           0xffffffff for grey images */
+    uint32_t reserved;
+    uint64_t dst;       /* byte offset of the decoded W*H frame from `out` (a multiple of 4) */
+} abub_png_frame;
+/* status[frame] after abub_png_decode_dev: 0 = decoded */
+#define ABUB_PNG_E_DESC 1       /* descriptor out of the stated buffer sizes */
+#define ABUB_PNG_E_HEADER 2     /* zlib header (RFC 1950) */
+#define ABUB_PNG_E_TRUNCATED 3  /* stream ends early */
+#define ABUB_PNG_E_BLOCKTYPE 4  /* deflate block type 3 */
+#define ABUB_PNG_E_STORED 5     /* stored block: LEN / NLEN mismatch */
+#define ABUB_PNG_E_SYMBOLS 6    /* more than 286 literal/length or 30 distance codes */
+#define ABUB_PNG_E_CODES 7      /* over-subscribed / incomplete code, bad repeat */
+#define ABUB_PNG_E_NOEOB 8      /* no end-of-block code */
+#define ABUB_PNG_E_CODE 9       /* invalid literal/length or distance code in the data */
+#define ABUB_PNG_E_DISTANCE 10  /* distance reaches before the start of the output */
+#define ABUB_PNG_E_TOOMUCH 11   /* more than H*(W+1) bytes */
+#define ABUB_PNG_E_TOOLITTLE 12 /* fewer */
+#define ABUB_PNG_E_ADLER 13     /* Adler-32 of the output differs from the trailer */
+#define ABUB_PNG_E_FILTER 14    /* filter type above 4 */
+/* bytes of `rawbuf` one frame takes (its inflated, still filtered scanlines) */
+size_t abub_png_raw_stride(int W, int H);
+/* files: the uploaded file bytes (4-byte aligned, files_bytes of them); frames[nframes], segs[nsegs], luts[nluts][256];
+ * zbuf / rawbuf: scratch (16-byte aligned; rawbuf >= nframes * abub_png_raw_stride); out: where frames go (out_bytes);
+ * status[nframes] (written for every frame).  W: a multiple of 4 in [4, 2048]. */
+int abub_png_decode_dev(const uint8_t *files, size_t files_bytes, const abub_png_frame *frames, int nframes,
+                        const abub_png_seg *segs, int nsegs, const uint8_t *luts, int nluts, int W, int H,
+                        uint8_t *zbuf, size_t zbuf_bytes, uint8_t *rawbuf, size_t rawbuf_bytes, uint8_t *out,
+                        size_t out_bytes, int32_t *status, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
