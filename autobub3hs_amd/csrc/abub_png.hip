@@ -27,12 +27,11 @@ namespace {
 constexpr int PNG_WIN = 32768;   // deflate history
 constexpr int PNG_CAP = 1024;    // output bytes one iteration may produce (ring = history + this)
 constexpr int PNG_RING = PNG_WIN + PNG_CAP;
-constexpr int PNG_INDW = 512;    // input ring in dwords (2 KiB, refilled 1 KiB at a time, one refill prefetched in registers)
+constexpr int PNG_INDW = 256;    // input ring in dwords (1 KiB, refilled 512 B at a time, one refill prefetched in registers)
 constexpr int PNG_FLUSH = 2048;  // unflushed output that triggers a flush
-constexpr int LIT_ROOT = 10, DIST_ROOT = 9;
+constexpr int LIT_ROOT = 10, DIST_ROOT = 8;
 constexpr int PNG_SHORT = 8;     // matches up to this length are copied by their own lane
 
-enum { K_LIT = 0, K_LEN = 1, K_EOB = 2, K_LONG = 3, K_BAD = 4 };
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t lane) { return __builtin_amdgcn_readlane(v, lane); }
@@ -149,38 +148,80 @@ __device__ __forceinline__ uint32_t canon_find(uint32_t rev, const Canon &C, uin
     return found;
 }
 
-__device__ __forceinline__ uint32_t lit_kind(uint32_t sym) { return sym < 256 ? K_LIT : sym == 256 ? K_EOB : sym < 286 ? K_LEN : K_BAD; }
-__device__ __forceinline__ uint32_t dist_kind(uint32_t sym) { return sym < 30 ? K_LIT : K_BAD; }
-// table entry: length (4 bits) | kind (3 bits) << 4 | symbol << 7
-__device__ __forceinline__ uint32_t entry_of(uint32_t l, uint32_t kind, uint32_t sym) { return l | (kind << 4) | (sym << 7); }
+// table entry (u32): code length (4 bits; 0 = no code of at most root bits starts here) | kind << 4 | extra bits << 6 |
+// base << 10 (literal: the byte; length / distance: the base value) | bit 31: a code longer than the root may match
+enum { T_LIT = 0, T_LEN = 1, T_EOB = 2, T_BAD = 3 };
+constexpr uint32_t T_LONG = 0x80000000u | (T_BAD << 4);
+__device__ __forceinline__ uint32_t lit_entry(uint32_t l, uint32_t sym)
+{
+    if (sym < 256)
+        return l | (T_LIT << 4) | (sym << 10);
+    if (sym == 256)
+        return l | (T_EOB << 4);
+    if (sym >= 286)
+        return T_BAD << 4;
+    const uint32_t i = sym - 257;
+    const uint32_t eb = (i < 8 || i == 28) ? 0u : (i - 4) >> 2;
+    const uint32_t base = i < 8 ? 3 + i : i == 28 ? 258u : 3 + ((4 + (i & 3)) << eb);
+    return l | (T_LEN << 4) | (eb << 6) | (base << 10);
+}
+__device__ __forceinline__ uint32_t dist_entry(uint32_t l, uint32_t sym)
+{
+    if (sym >= 30)
+        return T_BAD << 4;
+    const uint32_t eb = sym < 4 ? 0u : (sym - 2) >> 1;
+    const uint32_t base = sym < 4 ? 1 + sym : 1 + ((2 + (sym & 1)) << eb);
+    return l | (T_LIT << 4) | (eb << 6) | (base << 10);
+}
 
 // root table, one lane per entry: the entry's index bits are the next ROOT bits of the stream
 template <int ROOT, bool DIST>
-__device__ __forceinline__ void canon_table(const Canon &C, const uint16_t *sorted, uint16_t *tab, int lane)
+__device__ __forceinline__ void canon_table(const Canon &C, const uint16_t *sorted, uint32_t *tab, int lane)
 {
     for (int e = lane; e < (1 << ROOT); e += 64) {
         const uint32_t rev = __brev((uint32_t)e) >> (32 - ROOT);
         uint32_t pos;
         const uint32_t l = canon_find<1, ROOT, ROOT>(rev, C, pos);
-        uint32_t ent = entry_of(0, C.longer ? K_LONG : K_BAD, 0);
+        uint32_t ent = C.longer ? T_LONG : (uint32_t)(T_BAD << 4);
         if (l) {
             const uint32_t sym = sorted[pos];
-            ent = entry_of(l, DIST ? dist_kind(sym) : lit_kind(sym), sym);
+            ent = DIST ? dist_entry(l, sym) : lit_entry(l, sym);
         }
-        tab[e] = (uint16_t)ent;
+        tab[e] = ent;
+    }
+}
+// the part of a canonical code the rare path needs (codes longer than the root), kept in LDS between the blocks' headers
+struct CanonLds {
+    uint16_t first[16], count[16], offset[16];
+};
+__device__ __forceinline__ void canon_store(const Canon &C, CanonLds &D, int lane)
+{
+    // (uniform values: every lane writes the same)
+#pragma unroll
+    for (int l = 0; l < 16; ++l) {
+        D.first[l] = (uint16_t)C.first[l];
+        D.count[l] = (uint16_t)C.count[l];
+        D.offset[l] = (uint16_t)C.offset[l];
     }
 }
 // codes longer than the root: canonical compare per length on the next 15 bits
 template <int ROOT, bool DIST>
-__device__ __forceinline__ uint32_t canon_slow(uint32_t bits, const Canon &C, const uint16_t *sorted)
+__device__ __forceinline__ uint32_t canon_slow(uint32_t bits, const CanonLds &C, const uint16_t *sorted)
 {
     const uint32_t rev = __brev(bits) >> 17;
-    uint32_t pos;
-    const uint32_t l = canon_find<ROOT + 1, 15, 15>(rev, C, pos);
-    if (!l)
-        return entry_of(0, K_BAD, 0);
+    uint32_t found = 0, pos = 0;
+#pragma unroll
+    for (int l = ROOT + 1; l <= 15; ++l) {
+        const uint32_t idx = (rev >> (15 - l)) - C.first[l];
+        if (!found && idx < C.count[l]) {
+            found = l;
+            pos = C.offset[l] + idx;
+        }
+    }
+    if (!found)
+        return T_BAD << 4;
     const uint32_t sym = sorted[pos];
-    return entry_of(l, DIST ? dist_kind(sym) : lit_kind(sym), sym);
+    return DIST ? dist_entry(found, sym) : lit_entry(found, sym);
 }
 
 __device__ const uint8_t png_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -188,14 +229,17 @@ __device__ const uint8_t png_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 1
 struct InflateLds {
     alignas(16) uint8_t win[PNG_RING];
     alignas(16) uint32_t in[PNG_INDW];
-    uint16_t lit[1 << LIT_ROOT];
-    uint16_t dist[1 << DIST_ROOT];
+    uint32_t lit[1 << LIT_ROOT];   // while a block's header is read, its code lengths live here (hdr_lens() ...)
+    uint32_t dist[1 << DIST_ROOT];
     uint16_t slit[288];
     uint16_t sdist[32];
-    uint16_t scl[32];
-    uint8_t lens[320];
-    uint8_t cl[32];
+    CanonLds cl, cd;
 };
+// scratch of the header parse inside the (then dead) literal table: lens[320] | cl[32] | scl[32] (u16)
+__device__ __forceinline__ uint8_t *hdr_lens(InflateLds &L) { return (uint8_t *)L.lit; }
+__device__ __forceinline__ uint8_t *hdr_cl(InflateLds &L) { return (uint8_t *)L.lit + 320; }
+__device__ __forceinline__ uint16_t *hdr_scl(InflateLds &L) { return (uint16_t *)((uint8_t *)L.lit + 352); }
+static_assert(sizeof(InflateLds) <= 40960, "four inflate waves per CU");
 
 // ---- gather: IDAT chunks -> one zlib stream per frame ------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_png_gather(const uint8_t *__restrict__ files, uint64_t files_bytes,
@@ -257,8 +301,8 @@ struct InflateState {
     const uint8_t *z;  // the frame's zlib stream
     uint32_t zpad;     // its length rounded up to 16 (readable, zero-filled behind the stream)
     uint32_t nbits;    // its length in bits
-    uint32_t in_hi;    // the input ring holds the stream's bytes [in_hi - 2048, in_hi)
-    uint4 pf;          // bytes [in_hi + 16 * lane, + 16), requested ahead
+    uint32_t in_hi;    // the input ring holds the stream's bytes [in_hi - 1024, in_hi)
+    uint2 pf;          // bytes [in_hi + 8 * lane, + 8), requested ahead
     uint8_t *raw;      // output of this frame
     uint32_t rawLen;   // exactly this many bytes are expected
     uint32_t op, op_r; // output position, and the same modulo the ring
@@ -266,25 +310,25 @@ struct InflateState {
     uint32_t a1, a2;   // Adler-32 of the flushed bytes
 };
 
-__device__ __forceinline__ uint4 png_load16(const InflateState &S, uint32_t off)
+__device__ __forceinline__ uint2 png_load8(const InflateState &S, uint32_t off)
 {
-    uint4 v = {0, 0, 0, 0};
-    if (off + 16 <= S.zpad)
-        v = *(const uint4 *)(S.z + off);
+    uint2 v = {0, 0};
+    if (off + 8 <= S.zpad)
+        v = *(const uint2 *)(S.z + off);
     return v;
 }
 __device__ __forceinline__ void png_refill(InflateState &S, InflateLds &L, int lane)
 {
-    ((uint4 *)L.in)[((S.in_hi & (PNG_INDW * 4 - 1)) >> 4) + lane] = S.pf;
-    S.in_hi += 1024;
-    S.pf = png_load16(S, S.in_hi + 16 * lane);
+    ((uint2 *)L.in)[((S.in_hi & (PNG_INDW * 4 - 1)) >> 3) + lane] = S.pf;
+    S.in_hi += 512;
+    S.pf = png_load8(S, S.in_hi + 8 * lane);
     wave_sync();
 }
 // (re)start the input ring at bit position ip
 __device__ __forceinline__ void png_in_start(InflateState &S, InflateLds &L, uint32_t ip, int lane)
 {
-    S.in_hi = (ip >> 3) & ~1023u;
-    S.pf = png_load16(S, S.in_hi + 16 * lane);
+    S.in_hi = (ip >> 3) & ~511u;
+    S.pf = png_load8(S, S.in_hi + 8 * lane);
     png_refill(S, L, lane);
 }
 // the ring covers every dword a window read at bit positions ip .. ip + 63 touches (and 32-bit peeks at ip)
@@ -428,12 +472,15 @@ __global__ __launch_bounds__(64) void k_png_inflate(const uint8_t *__restrict__ 
             png_in_start(S, L, ip, lane);
             continue;
         }
-        // ---- code lengths of the block -> LDS lens[0 .. 288) literal/length, lens[288 .. 320) distance ----
+        // ---- code lengths of the block -> lens[0 .. 288) literal/length, lens[288 .. 320) distance (scratch inside L.lit) ----
+        uint8_t *const lens = hdr_lens(L);
         uint32_t hlit = 288, hdist = 32;
         if (btype == 1) {
-            for (int s = lane; s < 320; s += 64)
-                L.lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
+            for (int q = lane; q < 320; q += 64)
+                lens[q] = (uint8_t)(q < 144 ? 8 : q < 256 ? 9 : q < 280 ? 7 : q < 288 ? 8 : 5);
         } else {
+            uint8_t *const cl = hdr_cl(L);
+            uint16_t *const scl = hdr_scl(L);
             if (ip + 14 > S.nbits) {
                 err = ABUB_PNG_E_TRUNCATED;
                 break;
@@ -449,19 +496,19 @@ __global__ __launch_bounds__(64) void k_png_inflate(const uint8_t *__restrict__ 
             }
             png_ensure(S, L, ip, lane);
             if (lane < 32)
-                L.cl[lane] = 0;
+                cl[lane] = 0;
             wave_sync();
             if ((uint32_t)lane < hclen)
-                L.cl[png_cl_order[lane]] = (uint8_t)(png_bits32(L, ip + 3 * lane) & 7);
+                cl[png_cl_order[lane]] = (uint8_t)(png_bits32(L, ip + 3 * lane) & 7);
             wave_sync();
             ip += 3 * hclen;
-            uint32_t cll[1] = {lane < 19 ? (uint32_t)L.cl[lane] : 0u};
+            uint32_t cll[1] = {lane < 19 ? (uint32_t)cl[lane] : 0u};
             Canon CC;
             if (!canon_counts<1>(cll, CC, 7, false) || CC.count[1] + CC.count[2] + CC.count[3] + CC.count[4] + CC.count[5] + CC.count[6] + CC.count[7] == 0) {
                 err = ABUB_PNG_E_CODES;
                 break;
             }
-            canon_sort<1>(cll, CC, L.scl, lane);
+            canon_sort<1>(cll, CC, scl, lane);
             wave_sync();
             // the code-length code's 128-entry table lives in two registers per lane (entry e: lane e & 63, register e >> 6)
             uint32_t clt[2];
@@ -470,7 +517,7 @@ __global__ __launch_bounds__(64) void k_png_inflate(const uint8_t *__restrict__ 
                 const uint32_t rev = __brev((uint32_t)(lane + 64 * q)) >> 25;
                 uint32_t pos;
                 const uint32_t l = canon_find<1, 7, 7>(rev, CC, pos);
-                clt[q] = l ? (l | ((uint32_t)L.scl[pos] << 4)) : 0u;
+                clt[q] = l ? (l | ((uint32_t)scl[pos] << 4)) : 0u;
             }
             const uint32_t total = hlit + hdist;
             uint32_t n = 0, prev = 0;
@@ -508,9 +555,9 @@ __global__ __launch_bounds__(64) void k_png_inflate(const uint8_t *__restrict__ 
                     err = ABUB_PNG_E_CODES;
                     break;
                 }
-                for (uint32_t k = lane; k < rep; k += 64) { // literal/length lengths at lens[0 ..), distance lengths at lens[288 ..)
-                    const uint32_t s = n + k;
-                    L.lens[s < hlit ? s : 288 + (s - hlit)] = (uint8_t)val;
+                for (uint32_t k = lane; k < rep; k += 64) {
+                    const uint32_t q = n + k;
+                    lens[q < hlit ? q : 288 + (q - hlit)] = (uint8_t)val;
                 }
                 prev = val;
                 n += rep;
@@ -521,34 +568,32 @@ __global__ __launch_bounds__(64) void k_png_inflate(const uint8_t *__restrict__ 
                 err = ABUB_PNG_E_TRUNCATED;
                 break;
             }
-            wave_sync();
         }
         wave_sync();
         // ---- tables ----
-        Canon CL, CD;
         {
+            Canon CL, CD;
             uint32_t ll[5];
 #pragma unroll
             for (int c = 0; c < 5; ++c) {
-                const uint32_t s = c * 64 + lane;
-                ll[c] = s < hlit ? (uint32_t)L.lens[s] : 0u;
+                const uint32_t q = c * 64 + lane;
+                ll[c] = q < hlit ? (uint32_t)lens[q] : 0u;
             }
-            const uint32_t eob = rdl(ll[4], 0); // symbol 256
-            if (!canon_counts<5>(ll, CL, LIT_ROOT, true)) {
+            uint32_t dl[1] = {(uint32_t)lane < hdist ? (uint32_t)lens[288 + lane] : 0u};
+            wave_sync(); // (the lengths are in registers: the literal table may now overwrite them)
+            const uint32_t eobLen = rdl(ll[4], 0); // symbol 256
+            if (!canon_counts<5>(ll, CL, LIT_ROOT, true) || !canon_counts<1>(dl, CD, DIST_ROOT, true)) {
                 err = ABUB_PNG_E_CODES;
                 break;
             }
-            if (!eob) {
+            if (!eobLen) {
                 err = ABUB_PNG_E_NOEOB;
                 break;
             }
             canon_sort<5>(ll, CL, L.slit, lane);
-            uint32_t dl[1] = {(uint32_t)lane < hdist ? (uint32_t)L.lens[288 + lane] : 0u};
-            if (!canon_counts<1>(dl, CD, DIST_ROOT, true)) {
-                err = ABUB_PNG_E_CODES;
-                break;
-            }
             canon_sort<1>(dl, CD, L.sdist, lane);
+            canon_store(CL, L.cl, lane);
+            canon_store(CD, L.cd, lane);
             wave_sync();
             canon_table<LIT_ROOT, false>(CL, L.slit, L.lit, lane);
             canon_table<DIST_ROOT, true>(CD, L.sdist, L.dist, lane);
@@ -562,69 +607,76 @@ __global__ __launch_bounds__(64) void k_png_inflate(const uint8_t *__restrict__ 
                 err = ABUB_PNG_E_TRUNCATED;
                 break;
             }
+            // every lane: one token at bit offset ip + lane
             const uint32_t pos = ip + lane, w = pos >> 5, sh = pos & 31;
             const uint32_t d0 = L.in[w & (PNG_INDW - 1)], d1 = L.in[(w + 1) & (PNG_INDW - 1)], d2 = L.in[(w + 2) & (PNG_INDW - 1)];
             const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
-            const uint64_t W = ((uint64_t)hi << 32) | lo;
             uint32_t e = L.lit[lo & ((1u << LIT_ROOT) - 1)];
-            if (ballot(((e >> 4) & 7) == K_LONG)) {
-                if (((e >> 4) & 7) == K_LONG)
-                    e = canon_slow<LIT_ROOT, false>(lo, CL, L.slit);
+            if (ballot(e >> 31)) {
+                if (e >> 31)
+                    e = canon_slow<LIT_ROOT, false>(lo, L.cl, L.slit);
             }
-            uint32_t kind = (e >> 4) & 7, nb = e & 15;
-            const uint32_t sym = e >> 7;
-            uint32_t olen = kind == K_LIT ? 1u : 0u, dist = 0;
-            if (ballot(kind == K_LEN)) {
-                const uint32_t i = kind == K_LEN ? sym - 257 : 0u;
-                const uint32_t eb = (i < 8 || i == 28) ? 0u : (i - 4) >> 2;
-                const uint32_t base = i < 8 ? 3 + i : i == 28 ? 258u : 3 + ((4 + (i & 3)) << eb);
-                const uint32_t len = base + ((uint32_t)(W >> nb) & ((1u << eb) - 1));
-                const uint32_t nb2 = nb + eb;
-                const uint32_t w2 = (uint32_t)(W >> nb2);
+            uint32_t nb = e & 15, kind = (e >> 4) & 3;
+            const uint32_t base = (e >> 10) & 0x1fffffu;
+            uint32_t olen = kind == T_LIT ? 1u : 0u, dist = 0;
+            if (ballot(kind == T_LEN)) {
+                const uint32_t eb = (e >> 6) & 15;
+                const uint32_t len = base + __builtin_amdgcn_ubfe(lo, nb, eb);
+                const uint32_t nb2 = nb + eb;                              // <= 20
+                const uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, nb2); // the 32 bits behind the length code
                 uint32_t de = L.dist[w2 & ((1u << DIST_ROOT) - 1)];
-                if (ballot(kind == K_LEN && ((de >> 4) & 7) == K_LONG)) {
-                    if (kind == K_LEN && ((de >> 4) & 7) == K_LONG)
-                        de = canon_slow<DIST_ROOT, true>(w2, CD, L.sdist);
+                if (ballot(kind == T_LEN && (de >> 31))) {
+                    if (kind == T_LEN && (de >> 31))
+                        de = canon_slow<DIST_ROOT, true>(w2, L.cd, L.sdist);
                 }
-                const uint32_t dk = (de >> 4) & 7, dsym = de >> 7, dnb = de & 15;
-                const uint32_t deb = dsym < 4 ? 0u : (dsym - 2) >> 1;
-                const uint32_t dbase = dsym < 4 ? 1 + dsym : 1 + ((2 + (dsym & 1)) << deb);
-                const uint32_t nb3 = nb2 + dnb;
-                const uint32_t dd = dbase + ((uint32_t)(W >> nb3) & ((1u << deb) - 1));
-                if (kind == K_LEN) {
+                const uint32_t dnb = de & 15, deb = (de >> 6) & 15; // dnb + deb <= 28
+                const uint32_t dd = ((de >> 10) & 0x1fffffu) + __builtin_amdgcn_ubfe(w2, dnb, deb);
+                if (kind == T_LEN) {
                     olen = len;
                     dist = dd;
-                    nb = nb3 + deb;
-                    if (dk != K_LIT)
-                        kind = K_BAD;
+                    nb = nb2 + dnb + deb;
+                    if (((de >> 4) & 3) == T_BAD)
+                        kind = T_BAD;
                 }
             }
-            // ---- the chain of real tokens: s, s + n(s), ... ----
-            const uint32_t packed = nb | (kind << 6) | (olen << 9);
+            // ---- the chain of real tokens: s, s + n(s), ...  (an invalid code advances by one bit: looked at afterwards) ----
+            const uint32_t step = kind == T_BAD ? 1u : nb;
             uint64_t valid = 0;
-            uint32_t p = s, total = 0;
-            bool eob = false, capped = false;
-            while (p < 64) {
-                const uint32_t t = rdl(packed, p);
-                const uint32_t k = (t >> 6) & 7, ol = t >> 9;
-                if (k == K_BAD) {
-                    err = ABUB_PNG_E_CODE;
-                    break;
-                }
-                if (total + ol > (uint32_t)PNG_CAP) {
-                    capped = true;
-                    break;
-                }
+            uint32_t p = s;
+            do {
                 valid |= 1ull << p;
-                total += ol;
-                p += t & 63;
-                if (k == K_EOB) {
+                p += rdl(step, p);
+            } while (p < 64);
+            bool mine = (valid >> lane) & 1;
+            bool eob = false;
+            {
+                const uint64_t stop = ballot(mine && kind >= T_EOB); // end of block or an invalid code on the chain: what follows is not data
+                if (stop) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(stop);
+                    if (rdl(kind, j) == T_BAD) {
+                        err = ABUB_PNG_E_CODE;
+                        break;
+                    }
+                    valid &= (2ull << j) - 1;
+                    mine = (valid >> lane) & 1;
+                    p = j + rdl(nb, j);
                     eob = true;
-                    break;
                 }
             }
-            if (err)
-                break;
+            // ---- where the tokens' bytes go ----
+            const uint32_t ol = mine ? olen : 0u;
+            const uint32_t incl = wave_incl_scan(ol);
+            uint32_t off = incl - ol, total = rdl(incl, 63);
+            bool capped = false;
+            if (total > (uint32_t)PNG_CAP) { // (runs of long matches: keep the tokens that fit, the next iteration starts at the first one left)
+                const uint64_t keep = ballot(mine && incl <= (uint32_t)PNG_CAP);
+                p = (uint32_t)__builtin_ctzll(valid & ~keep);
+                valid = keep;
+                mine = (valid >> lane) & 1;
+                total = rdl(incl, 63 - (uint32_t)__builtin_clzll(keep));
+                eob = false;
+                capped = true;
+            }
             if (eob || capped) {
                 ip += p;
                 s = 0;
@@ -640,18 +692,12 @@ __global__ __launch_bounds__(64) void k_png_inflate(const uint8_t *__restrict__ 
                 err = ABUB_PNG_E_TOOMUCH;
                 break;
             }
-            const bool mine = (valid >> lane) & 1;
-            const bool isMatch = mine && kind == K_LEN;
+            const bool isMatch = mine && kind == T_LEN;
             const uint64_t mm = ballot(isMatch);
-            uint32_t off;
-            if (!mm)
-                off = below(valid); // literals only (an end-of-block token is the chain's last)
-            else {
-                const uint32_t ol = mine ? olen : 0u;
-                off = wave_incl_scan(ol) - ol;
-            }
-            if (mine && kind == K_LIT)
-                L.win[ring_wrap(S.op_r + off)] = (uint8_t)sym;
+            const bool nowrap = S.op_r + (uint32_t)PNG_CAP + 264 <= (uint32_t)PNG_RING; // no destination of this iteration wraps
+            const uint32_t dst = nowrap ? S.op_r + off : ring_wrap(S.op_r + off);
+            if (mine && kind == T_LIT)
+                L.win[dst] = (uint8_t)base;
             if (mm) {
                 if (ballot(isMatch && dist > S.op + off)) {
                     err = ABUB_PNG_E_DISTANCE;
@@ -661,34 +707,54 @@ __global__ __launch_bounds__(64) void k_png_inflate(const uint8_t *__restrict__ 
                 // a match whose source ends behind m0 may read what an earlier match of this iteration writes
                 const bool dep = isMatch && (int)(off + olen) - (int)dist > (int)m0;
                 const bool own = isMatch && !dep && olen <= (uint32_t)PNG_SHORT;
+                int sidx = (int)(S.op_r + off) - (int)dist; // > -RING
+                if (sidx < 0)
+                    sidx += PNG_RING;
+                else if (sidx >= PNG_RING)
+                    sidx -= PNG_RING;
                 wave_sync();
-                if (ballot(own)) {
-                    uint32_t sidx = S.op_r + off + PNG_RING - dist; // < 2 * RING + CAP
-                    sidx = ring_wrap(ring_wrap(sidx));
-                    const uint32_t didx = ring_wrap(S.op_r + off);
-                    uint32_t b[PNG_SHORT];
+                const uint64_t ownm = ballot(own);
+                if (ownm) {
+                    if (nowrap && !ballot(own && sidx + PNG_SHORT > PNG_RING)) {
+                        // the common case: no byte of these copies wraps.  Every match has 3 bytes; the longer ones go on.
+                        if (own) {
+                            const uint8_t b0 = L.win[sidx], b1 = L.win[sidx + 1], b2 = L.win[sidx + 2];
+                            L.win[dst] = b0;
+                            L.win[dst + 1] = b1;
+                            L.win[dst + 2] = b2;
+                        }
 #pragma unroll
-                    for (int k = 0; k < PNG_SHORT; ++k)
-                        b[k] = (own && (uint32_t)k < olen) ? (uint32_t)L.win[ring_wrap(sidx + k)] : 0u;
+                        for (int k = 3; k < PNG_SHORT; ++k) {
+                            if (!ballot(own && olen > (uint32_t)k))
+                                break;
+                            if (own && olen > (uint32_t)k)
+                                L.win[dst + k] = L.win[sidx + k];
+                        }
+                    } else {
+                        uint32_t b[PNG_SHORT];
 #pragma unroll
-                    for (int k = 0; k < PNG_SHORT; ++k)
-                        if (own && (uint32_t)k < olen)
-                            L.win[ring_wrap(didx + k)] = (uint8_t)b[k];
+                        for (int k = 0; k < PNG_SHORT; ++k)
+                            b[k] = (own && (uint32_t)k < olen) ? (uint32_t)L.win[ring_wrap((uint32_t)sidx + k)] : 0u;
+#pragma unroll
+                        for (int k = 0; k < PNG_SHORT; ++k)
+                            if (own && (uint32_t)k < olen)
+                                L.win[ring_wrap(ring_wrap(S.op_r + off) + k)] = (uint8_t)b[k];
+                    }
                 }
-                uint64_t rest = ballot(isMatch && !own);
+                uint64_t rest = mm & ~ownm;
                 while (rest) {
                     const uint32_t j = (uint32_t)__builtin_ctzll(rest);
                     rest &= rest - 1;
                     const uint32_t o = rdl(off, j), len = rdl(olen, j), d = rdl(dist, j);
                     wave_sync();
                     const uint32_t dst0 = ring_wrap(S.op_r + o);
-                    const uint32_t src0 = ring_wrap(ring_wrap(S.op_r + o + PNG_RING - d));
+                    const uint32_t src0 = rdl((uint32_t)sidx, j);
                     const float rcp = 1.0f / (float)d;
                     for (uint32_t k0 = 0; k0 < len; k0 += 64) {
                         const uint32_t k = k0 + lane;
                         uint32_t r = k;
                         if (d < len) { // overlapping: byte k repeats the pattern of d bytes
-                            uint32_t q = (uint32_t)((float)k * rcp);
+                            const uint32_t q = (uint32_t)((float)k * rcp);
                             int rr = (int)k - (int)(q * d);
                             if (rr < 0)
                                 rr += (int)d;
