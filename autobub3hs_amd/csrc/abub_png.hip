@@ -27,7 +27,8 @@ namespace {
 constexpr int PNG_WIN = 32768;   // deflate history
 constexpr int PNG_CAP = 1024;    // output bytes one iteration may produce (ring = history + this)
 constexpr int PNG_RING = PNG_WIN + PNG_CAP;
-constexpr int PNG_INDW = 256;    // input ring in dwords (1 KiB, refilled 512 B at a time, one refill prefetched in registers)
+constexpr int PNG_INDW = 128;    // input ring in dwords (512 B, refilled 256 B at a time, one refill prefetched in registers)
+constexpr int PNG_NSLOT = 2;     // token records in flight between the parsing and the writing wave
 constexpr int PNG_FLUSH = 2048;  // unflushed output that triggers a flush
 constexpr int LIT_ROOT = 10, DIST_ROOT = 8;
 constexpr int PNG_SHORT = 8;     // matches up to this length are copied by their own lane
@@ -226,6 +227,14 @@ __device__ __forceinline__ uint32_t canon_slow(uint32_t bits, const CanonLds &C,
 
 __device__ const uint8_t png_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
+// what the parsing wave hands to the writing wave
+enum { REC_TOKENS = 0, REC_STORED = 1, REC_END = 2, REC_ERROR = 3 };
+struct TokSlot {
+    uint32_t tok[64]; // per bit offset of the window: literal = byte << 1; match = 1 | length << 1 | distance << 10
+    uint32_t vlo, vhi; // which of them are tokens of the stream
+    uint32_t kind;     // REC_* (REC_STORED: | length << 2)
+    uint32_t aux;      // REC_STORED: byte offset of the data in the stream; REC_END: the stream's Adler-32; REC_ERROR: status
+};
 struct InflateLds {
     alignas(16) uint8_t win[PNG_RING];
     alignas(16) uint32_t in[PNG_INDW];
@@ -234,6 +243,8 @@ struct InflateLds {
     uint16_t slit[288];
     uint16_t sdist[32];
     CanonLds cl, cd;
+    TokSlot q[PNG_NSLOT];
+    uint32_t q_head, q_tail, q_abort, q_pad;
 };
 // scratch of the header parse inside the (then dead) literal table: lens[320] | cl[32] | scl[32] (u16)
 __device__ __forceinline__ uint8_t *hdr_lens(InflateLds &L) { return (uint8_t *)L.lit; }
@@ -296,13 +307,17 @@ __global__ __launch_bounds__(256) void k_png_gather(const uint8_t *__restrict__ 
         status[f] = 0;
 }
 
-// ---- inflate: one wave per frame -----------------------------------------------------------------------------------
-struct InflateState {
+// ---- inflate: one stream per workgroup; one wave does everything, or a parsing and a writing wave share the work ----
+struct Parser {
     const uint8_t *z;  // the frame's zlib stream
+    uint32_t zlen;
     uint32_t zpad;     // its length rounded up to 16 (readable, zero-filled behind the stream)
     uint32_t nbits;    // its length in bits
-    uint32_t in_hi;    // the input ring holds the stream's bytes [in_hi - 1024, in_hi)
-    uint2 pf;          // bytes [in_hi + 8 * lane, + 8), requested ahead
+    uint32_t in_hi;    // the input ring holds the stream's bytes [in_hi - 512, in_hi)
+    uint32_t pf;       // bytes [in_hi + 4 * lane, + 4), requested ahead
+};
+struct Writer {
+    const uint8_t *z;  // (stored blocks are copied from the stream)
     uint8_t *raw;      // output of this frame
     uint32_t rawLen;   // exactly this many bytes are expected
     uint32_t op, op_r; // output position, and the same modulo the ring
@@ -310,33 +325,33 @@ struct InflateState {
     uint32_t a1, a2;   // Adler-32 of the flushed bytes
 };
 
-__device__ __forceinline__ uint2 png_load8(const InflateState &S, uint32_t off)
+__device__ __forceinline__ uint32_t png_load4(const Parser &P, uint32_t off)
 {
-    uint2 v = {0, 0};
-    if (off + 8 <= S.zpad)
-        v = *(const uint2 *)(S.z + off);
+    uint32_t v = 0;
+    if (off + 4 <= P.zpad)
+        v = *(const uint32_t *)(P.z + off);
     return v;
 }
-__device__ __forceinline__ void png_refill(InflateState &S, InflateLds &L, int lane)
+__device__ __forceinline__ void png_refill(Parser &P, InflateLds &L, int lane)
 {
-    ((uint2 *)L.in)[((S.in_hi & (PNG_INDW * 4 - 1)) >> 3) + lane] = S.pf;
-    S.in_hi += 512;
-    S.pf = png_load8(S, S.in_hi + 8 * lane);
+    L.in[((P.in_hi & (PNG_INDW * 4 - 1)) >> 2) + lane] = P.pf;
+    P.in_hi += 256;
+    P.pf = png_load4(P, P.in_hi + 4 * lane);
     wave_sync();
 }
 // (re)start the input ring at bit position ip
-__device__ __forceinline__ void png_in_start(InflateState &S, InflateLds &L, uint32_t ip, int lane)
+__device__ __forceinline__ void png_in_start(Parser &P, InflateLds &L, uint32_t ip, int lane)
 {
-    S.in_hi = (ip >> 3) & ~511u;
-    S.pf = png_load8(S, S.in_hi + 8 * lane);
-    png_refill(S, L, lane);
+    P.in_hi = (ip >> 3) & ~255u;
+    P.pf = png_load4(P, P.in_hi + 4 * lane);
+    png_refill(P, L, lane);
 }
 // the ring covers every dword a window read at bit positions ip .. ip + 63 touches (and 32-bit peeks at ip)
-__device__ __forceinline__ void png_ensure(InflateState &S, InflateLds &L, uint32_t ip, int lane)
+__device__ __forceinline__ void png_ensure(Parser &P, InflateLds &L, uint32_t ip, int lane)
 {
     const uint32_t need = ((ip + 127) >> 5) * 4 + 12;
-    while (need > S.in_hi)
-        png_refill(S, L, lane);
+    while (need > P.in_hi)
+        png_refill(P, L, lane);
 }
 // 32 bits of the stream at bit position pos (any lane-specific pos inside the ensured range)
 __device__ __forceinline__ uint32_t png_bits32(const InflateLds &L, uint32_t pos)
@@ -347,7 +362,7 @@ __device__ __forceinline__ uint32_t png_bits32(const InflateLds &L, uint32_t pos
 __device__ __forceinline__ uint32_t ring_wrap(uint32_t i) { return i >= (uint32_t)PNG_RING ? i - PNG_RING : i; }
 
 // ring -> HBM for the bytes [fp, upto), Adler-32 on the way; upto is a multiple of 16 unless `last`
-__device__ __forceinline__ void png_flush(InflateState &S, InflateLds &L, uint32_t upto, bool last, int lane)
+__device__ __forceinline__ void png_flush(Writer &S, InflateLds &L, uint32_t upto, bool last, int lane)
 {
     const uint32_t n = upto - S.fp;
     if (!n)
@@ -382,7 +397,7 @@ __device__ __forceinline__ void png_flush(InflateState &S, InflateLds &L, uint32
     S.a1 = (S.a1 + S1) % 65521u;
     S.fp = upto;
 }
-__device__ __forceinline__ void png_advance(InflateState &S, InflateLds &L, uint32_t total, int lane)
+__device__ __forceinline__ void png_advance(Writer &S, InflateLds &L, uint32_t total, int lane)
 {
     S.op += total;
     S.op_r = ring_wrap(S.op_r + total);
@@ -392,221 +407,373 @@ __device__ __forceinline__ void png_advance(InflateState &S, InflateLds &L, uint
     }
 }
 
-__global__ __launch_bounds__(64) void k_png_inflate(const uint8_t *__restrict__ zbuf, const abub_png_frame *__restrict__ frames,
-                                                    uint32_t rawLen, uint64_t rawStride, uint8_t *__restrict__ rawbuf,
-                                                    int32_t *__restrict__ status)
+// ---- the writing side: tokens -> the history ring ----
+// One window's tokens (valid = which bit offsets hold one; tok as in TokSlot).  Returns a status.
+__device__ __forceinline__ int png_apply(Writer &S, InflateLds &L, uint64_t valid, uint32_t tok, int lane)
 {
-    __shared__ InflateLds L;
-    const int f = blockIdx.x, lane = threadIdx.x;
-    if (status[f] != 0) // (refused by the gather kernel; uniform)
-        return;
-    const abub_png_frame fr = frames[f];
-    InflateState S;
-    S.z = zbuf + fr.zoff;
-    S.zpad = (fr.zlen + 15) & ~15u;
-    S.nbits = fr.zlen * 8;
-    S.raw = rawbuf + (uint64_t)f * rawStride;
-    S.rawLen = rawLen;
-    S.op = S.op_r = S.fp = 0;
-    S.a1 = 1;
-    S.a2 = 0;
-    int err = 0;
+    const bool mine = (valid >> lane) & 1;
+    const bool isM = tok & 1;
+    const uint32_t olen = mine ? (isM ? (tok >> 1) & 511u : 1u) : 0u;
+    const uint32_t dist = tok >> 10, lit = (tok >> 1) & 255u;
+    const uint32_t incl = wave_incl_scan(olen);
+    uint64_t todo = valid;
+    uint32_t consumed = 0;
+    do {
+        // the tokens of this pass: the whole window unless it carries more than PNG_CAP bytes (runs of long matches)
+        const bool sel = ((todo >> lane) & 1) && incl - consumed <= (uint32_t)PNG_CAP;
+        const uint64_t selm = ballot(sel);
+        const uint32_t total = rdl(incl, 63 - (uint32_t)__builtin_clzll(selm)) - consumed;
+        const uint32_t off = incl - olen - consumed;
+        if (S.op + total > S.rawLen)
+            return ABUB_PNG_E_TOOMUCH;
+        const bool isMatch = sel && isM;
+        const uint64_t mm = ballot(isMatch);
+        const bool nowrap = S.op_r + (uint32_t)PNG_CAP + 264 <= (uint32_t)PNG_RING; // no destination of this pass wraps
+        const uint32_t dst = nowrap ? S.op_r + off : ring_wrap(S.op_r + off);
+        if (sel && !isM)
+            L.win[dst] = (uint8_t)lit;
+        if (mm) {
+            if (ballot(isMatch && dist > S.op + off))
+                return ABUB_PNG_E_DISTANCE;
+            const uint32_t m0 = rdl(off, (uint32_t)__builtin_ctzll(mm)); // output offset of the pass's first match
+            // a match whose source ends behind m0 may read what an earlier match of this pass writes
+            const bool dep = isMatch && (int)(off + olen) - (int)dist > (int)m0;
+            const bool own = isMatch && !dep && olen <= (uint32_t)PNG_SHORT;
+            int sidx = (int)(S.op_r + off) - (int)dist; // > -RING
+            if (sidx < 0)
+                sidx += PNG_RING;
+            else if (sidx >= PNG_RING)
+                sidx -= PNG_RING;
+            wave_sync();
+            const uint64_t ownm = ballot(own);
+            if (ownm) {
+                if (nowrap && !ballot(own && sidx + PNG_SHORT > PNG_RING)) {
+                    // the common case: no byte of these copies wraps.  All reads first (bytes behind a match's end are read
+                    // and dropped), then the writes: one LDS round trip for the whole pass.
+                    const bool any4 = ballot(own && olen > 3), any6 = ballot(own && olen > 5);
+                    uint32_t b[PNG_SHORT];
+                    if (own) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            b[k] = L.win[sidx + k];
+                        if (any4) {
+                            b[3] = L.win[sidx + 3];
+                            b[4] = L.win[sidx + 4];
+                        }
+                        if (any6) {
+                            b[5] = L.win[sidx + 5];
+                            b[6] = L.win[sidx + 6];
+                            b[7] = L.win[sidx + 7];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            L.win[dst + k] = (uint8_t)b[k];
+                        if (any4) {
+                            if (olen > 3)
+                                L.win[dst + 3] = (uint8_t)b[3];
+                            if (olen > 4)
+                                L.win[dst + 4] = (uint8_t)b[4];
+                        }
+                        if (any6) {
+                            if (olen > 5)
+                                L.win[dst + 5] = (uint8_t)b[5];
+                            if (olen > 6)
+                                L.win[dst + 6] = (uint8_t)b[6];
+                            if (olen > 7)
+                                L.win[dst + 7] = (uint8_t)b[7];
+                        }
+                    }
+                } else {
+                    uint32_t b[PNG_SHORT];
+#pragma unroll
+                    for (int k = 0; k < PNG_SHORT; ++k)
+                        b[k] = (own && (uint32_t)k < olen) ? (uint32_t)L.win[ring_wrap((uint32_t)sidx + k)] : 0u;
+#pragma unroll
+                    for (int k = 0; k < PNG_SHORT; ++k)
+                        if (own && (uint32_t)k < olen)
+                            L.win[ring_wrap(ring_wrap(S.op_r + off) + k)] = (uint8_t)b[k];
+                }
+            }
+            uint64_t rest = mm & ~ownm;
+            while (rest) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(rest);
+                rest &= rest - 1;
+                const uint32_t o = rdl(off, j), len = rdl(olen, j), d = rdl(dist, j);
+                wave_sync();
+                const uint32_t dst0 = ring_wrap(S.op_r + o);
+                const uint32_t src0 = rdl((uint32_t)sidx, j);
+                const float rcp = 1.0f / (float)d;
+                for (uint32_t k0 = 0; k0 < len; k0 += 64) {
+                    const uint32_t k = k0 + lane;
+                    uint32_t r = k;
+                    if (d < len) { // overlapping: byte k repeats the pattern of d bytes
+                        const uint32_t q = (uint32_t)((float)k * rcp);
+                        int rr = (int)k - (int)(q * d);
+                        if (rr < 0)
+                            rr += (int)d;
+                        if (rr >= (int)d)
+                            rr -= (int)d;
+                        r = (uint32_t)rr;
+                    }
+                    if (k < len) {
+                        const uint8_t byte = L.win[ring_wrap(src0 + r)];
+                        L.win[ring_wrap(dst0 + k)] = byte;
+                    }
+                }
+            }
+        }
+        png_advance(S, L, total, lane);
+        todo &= ~selm;
+        consumed += total;
+    } while (todo);
+    return 0;
+}
+// a stored block's bytes, straight from the stream
+__device__ __forceinline__ int png_apply_stored(Writer &S, InflateLds &L, uint32_t bp, uint32_t len, int lane)
+{
+    if (S.op + len > S.rawLen)
+        return ABUB_PNG_E_TOOMUCH;
+    for (uint32_t rem = len; rem;) {
+        const uint32_t chunk = min(rem, (uint32_t)PNG_CAP);
+        for (uint32_t k = lane; k < chunk; k += 64)
+            L.win[ring_wrap(S.op_r + k)] = S.z[bp + k];
+        bp += chunk;
+        rem -= chunk;
+        png_advance(S, L, chunk, lane);
+    }
+    return 0;
+}
+// the end of the stream: everything out, size and checksum as zlib checks them
+__device__ __forceinline__ int png_apply_end(Writer &S, InflateLds &L, uint32_t adler, int lane)
+{
+    wave_sync();
+    png_flush(S, L, S.op, true, lane);
+    if (S.op != S.rawLen)
+        return ABUB_PNG_E_TOOLITTLE;
+    return adler == ((S.a2 << 16) | S.a1) ? 0 : ABUB_PNG_E_ADLER;
+}
+
+// ---- the hand-over between the two waves ----
+__device__ __forceinline__ uint32_t q_ld(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void q_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+constexpr uint32_t PNG_SPINS = 1u << 19; // x >= 64 cycles: a wave that waits this long has lost its partner
+
+// The receiving end of the parser's records: TWO = false applies them on the spot (one wave does everything), TWO = true
+// puts them into the LDS queue for the writing wave.
+template <bool TWO>
+struct Sink {
+    InflateLds &L;
+    Writer *W;      // !TWO
+    uint32_t head;  // TWO
+    int lane;
+    int dbg;        // measurement only: 1 = the records are dropped (what the parsing alone costs)
+    // returns a status for !TWO; for TWO: 0, or -1 when the writing wave has gone (the parser then just stops)
+    __device__ __forceinline__ int put(uint32_t kind, uint32_t aux, uint64_t valid, uint32_t tok)
+    {
+        if (!TWO) {
+            const uint32_t k = kind & 3;
+            if (dbg == 1)
+                return 0;
+            if (k == REC_TOKENS)
+                return png_apply(*W, L, valid, tok, lane);
+            if (k == REC_STORED)
+                return png_apply_stored(*W, L, aux, kind >> 2, lane);
+            if (k == REC_END)
+                return png_apply_end(*W, L, aux, lane);
+            return (int)aux;
+        }
+        uint32_t spins = 0;
+        while (head - q_ld(&L.q_tail) >= (uint32_t)PNG_NSLOT) {
+            if (q_ld(&L.q_abort) || ++spins > PNG_SPINS)
+                return -1;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        TokSlot &sl = L.q[head % PNG_NSLOT];
+        sl.tok[lane] = tok;
+        if (lane == 0) {
+            sl.vlo = (uint32_t)valid;
+            sl.vhi = (uint32_t)(valid >> 32);
+            sl.kind = kind;
+            sl.aux = aux;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        ++head;
+        if (lane == 0)
+            q_st(&L.q_head, head);
+        return 0;
+    }
+};
+
+// ---- the parsing side ----
+// tables of one block (btype 1: the fixed code, 2: the code lengths in the stream at ip); returns a status
+__device__ __forceinline__ int png_block_tables(Parser &P, InflateLds &L, uint32_t &ip, uint32_t btype, int lane)
+{
+    uint8_t *const lens = hdr_lens(L); // lens[0 .. 288) literal/length, lens[288 .. 320) distance
+    uint32_t hlit = 288, hdist = 32;
+    if (btype == 1) {
+        for (int q = lane; q < 320; q += 64)
+            lens[q] = (uint8_t)(q < 144 ? 8 : q < 256 ? 9 : q < 280 ? 7 : q < 288 ? 8 : 5);
+    } else {
+        uint8_t *const cl = hdr_cl(L);
+        uint16_t *const scl = hdr_scl(L);
+        if (ip + 14 > P.nbits)
+            return ABUB_PNG_E_TRUNCATED;
+        const uint32_t hv = rfl(png_bits32(L, ip));
+        hlit = (hv & 31) + 257;
+        hdist = ((hv >> 5) & 31) + 1;
+        const uint32_t hclen = ((hv >> 10) & 15) + 4;
+        ip += 14;
+        if (hlit > 286 || hdist > 30)
+            return ABUB_PNG_E_SYMBOLS;
+        png_ensure(P, L, ip, lane);
+        if (lane < 32)
+            cl[lane] = 0;
+        wave_sync();
+        if ((uint32_t)lane < hclen)
+            cl[png_cl_order[lane]] = (uint8_t)(png_bits32(L, ip + 3 * lane) & 7);
+        wave_sync();
+        ip += 3 * hclen;
+        uint32_t cll[1] = {lane < 19 ? (uint32_t)cl[lane] : 0u};
+        Canon CC;
+        if (!canon_counts<1>(cll, CC, 7, false) || CC.count[1] + CC.count[2] + CC.count[3] + CC.count[4] + CC.count[5] + CC.count[6] + CC.count[7] == 0)
+            return ABUB_PNG_E_CODES;
+        canon_sort<1>(cll, CC, scl, lane);
+        wave_sync();
+        // the code-length code's 128-entry table lives in two registers per lane (entry e: lane e & 63, register e >> 6)
+        uint32_t clt[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t rev = __brev((uint32_t)(lane + 64 * q)) >> 25;
+            uint32_t pos;
+            const uint32_t l = canon_find<1, 7, 7>(rev, CC, pos);
+            clt[q] = l ? (l | ((uint32_t)scl[pos] << 4)) : 0u;
+        }
+        const uint32_t total = hlit + hdist;
+        uint32_t n = 0, prev = 0;
+        while (n < total) {
+            png_ensure(P, L, ip, lane);
+            uint32_t v = rfl(png_bits32(L, ip));
+            const uint32_t idx = v & 127;
+            const uint32_t ent = idx < 64 ? rdl(clt[0], idx) : rdl(clt[1], idx - 64);
+            const uint32_t l = ent & 15, sym = ent >> 4;
+            if (!l)
+                return ABUB_PNG_E_CODES;
+            v >>= l;
+            ip += l;
+            uint32_t rep = 1, val = sym;
+            if (sym == 16) {
+                if (!n)
+                    return ABUB_PNG_E_CODES;
+                rep = 3 + (v & 3);
+                val = prev;
+                ip += 2;
+            } else if (sym == 17) {
+                rep = 3 + (v & 7);
+                val = 0;
+                ip += 3;
+            } else if (sym == 18) {
+                rep = 11 + (v & 127);
+                val = 0;
+                ip += 7;
+            }
+            if (n + rep > total)
+                return ABUB_PNG_E_CODES;
+            for (uint32_t k = lane; k < rep; k += 64) {
+                const uint32_t q = n + k;
+                lens[q < hlit ? q : 288 + (q - hlit)] = (uint8_t)val;
+            }
+            prev = val;
+            n += rep;
+        }
+        if (ip > P.nbits)
+            return ABUB_PNG_E_TRUNCATED;
+    }
+    wave_sync();
+    Canon CL, CD;
+    uint32_t ll[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const uint32_t q = c * 64 + lane;
+        ll[c] = q < hlit ? (uint32_t)lens[q] : 0u;
+    }
+    uint32_t dl[1] = {(uint32_t)lane < hdist ? (uint32_t)lens[288 + lane] : 0u};
+    wave_sync(); // (the lengths are in registers: the literal table may now overwrite them)
+    const uint32_t eobLen = rdl(ll[4], 0); // symbol 256
+    if (!canon_counts<5>(ll, CL, LIT_ROOT, true) || !canon_counts<1>(dl, CD, DIST_ROOT, true))
+        return ABUB_PNG_E_CODES;
+    if (!eobLen)
+        return ABUB_PNG_E_NOEOB;
+    canon_sort<5>(ll, CL, L.slit, lane);
+    canon_sort<1>(dl, CD, L.sdist, lane);
+    canon_store(CL, L.cl, lane);
+    canon_store(CD, L.cd, lane);
+    wave_sync();
+    canon_table<LIT_ROOT, false>(CL, L.slit, L.lit, lane);
+    canon_table<DIST_ROOT, true>(CD, L.sdist, L.dist, lane);
+    wave_sync();
+    return 0;
+}
+
+// the whole stream: headers, tables, tokens -> records for `sink`.  Returns a status (0 after REC_END went out; -1 when the
+// sink has gone).
+template <bool TWO>
+__device__ __forceinline__ int png_parse(Parser &P, InflateLds &L, Sink<TWO> &sink, int lane)
+{
     uint32_t ip = 16;
-    png_in_start(S, L, 0, lane);
-    png_ensure(S, L, 0, lane);
-    if (fr.zlen < 6 || fr.zlen >= (1u << 28))
-        err = ABUB_PNG_E_TRUNCATED;
-    else {
+    png_in_start(P, L, 0, lane);
+    png_ensure(P, L, 0, lane);
+    if (P.zlen < 6 || P.zlen >= (1u << 28))
+        return ABUB_PNG_E_TRUNCATED;
+    {
         const uint32_t h = rfl(png_bits32(L, 0));
         const uint32_t cmf = h & 255, flg = (h >> 8) & 255;
         if ((cmf & 15) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 || (flg & 0x20))
-            err = ABUB_PNG_E_HEADER;
+            return ABUB_PNG_E_HEADER;
     }
     bool final = false;
-    while (!err && !final) {
-        png_ensure(S, L, ip, lane);
-        if (ip + 3 > S.nbits) {
-            err = ABUB_PNG_E_TRUNCATED;
-            break;
-        }
+    while (!final) {
+        png_ensure(P, L, ip, lane);
+        if (ip + 3 > P.nbits)
+            return ABUB_PNG_E_TRUNCATED;
         uint32_t hv = rfl(png_bits32(L, ip));
         final = hv & 1;
         const uint32_t btype = (hv >> 1) & 3;
         ip += 3;
-        if (btype == 3) {
-            err = ABUB_PNG_E_BLOCKTYPE;
-            break;
-        }
-        if (btype == 0) { // stored: straight from the stream into the ring
+        if (btype == 3)
+            return ABUB_PNG_E_BLOCKTYPE;
+        if (btype == 0) { // stored: the writing side copies it out of the stream
             ip = (ip + 7) & ~7u;
-            png_ensure(S, L, ip, lane);
-            if (ip + 32 > S.nbits) {
-                err = ABUB_PNG_E_TRUNCATED;
-                break;
-            }
+            png_ensure(P, L, ip, lane);
+            if (ip + 32 > P.nbits)
+                return ABUB_PNG_E_TRUNCATED;
             hv = rfl(png_bits32(L, ip));
             const uint32_t len = hv & 0xffff;
-            if ((len ^ (hv >> 16)) != 0xffff) {
-                err = ABUB_PNG_E_STORED;
-                break;
-            }
+            if ((len ^ (hv >> 16)) != 0xffff)
+                return ABUB_PNG_E_STORED;
             ip += 32;
-            uint32_t bp = ip >> 3;
-            if ((uint64_t)bp + len > fr.zlen) {
-                err = ABUB_PNG_E_TRUNCATED;
-                break;
+            const uint32_t bp = ip >> 3;
+            if ((uint64_t)bp + len > P.zlen)
+                return ABUB_PNG_E_TRUNCATED;
+            if (len) {
+                const int rc = sink.put(REC_STORED | (len << 2), bp, 0, 0);
+                if (rc)
+                    return rc;
             }
-            if (S.op + len > S.rawLen) {
-                err = ABUB_PNG_E_TOOMUCH;
-                break;
-            }
-            for (uint32_t rem = len; rem;) {
-                const uint32_t chunk = min(rem, (uint32_t)PNG_CAP);
-                for (uint32_t k = lane; k < chunk; k += 64)
-                    L.win[ring_wrap(S.op_r + k)] = S.z[bp + k];
-                bp += chunk;
-                rem -= chunk;
-                png_advance(S, L, chunk, lane);
-            }
-            ip = bp * 8;
-            png_in_start(S, L, ip, lane);
+            ip = (bp + len) * 8;
+            png_in_start(P, L, ip, lane);
             continue;
         }
-        // ---- code lengths of the block -> lens[0 .. 288) literal/length, lens[288 .. 320) distance (scratch inside L.lit) ----
-        uint8_t *const lens = hdr_lens(L);
-        uint32_t hlit = 288, hdist = 32;
-        if (btype == 1) {
-            for (int q = lane; q < 320; q += 64)
-                lens[q] = (uint8_t)(q < 144 ? 8 : q < 256 ? 9 : q < 280 ? 7 : q < 288 ? 8 : 5);
-        } else {
-            uint8_t *const cl = hdr_cl(L);
-            uint16_t *const scl = hdr_scl(L);
-            if (ip + 14 > S.nbits) {
-                err = ABUB_PNG_E_TRUNCATED;
-                break;
-            }
-            hv = rfl(png_bits32(L, ip));
-            hlit = (hv & 31) + 257;
-            hdist = ((hv >> 5) & 31) + 1;
-            const uint32_t hclen = ((hv >> 10) & 15) + 4;
-            ip += 14;
-            if (hlit > 286 || hdist > 30) {
-                err = ABUB_PNG_E_SYMBOLS;
-                break;
-            }
-            png_ensure(S, L, ip, lane);
-            if (lane < 32)
-                cl[lane] = 0;
-            wave_sync();
-            if ((uint32_t)lane < hclen)
-                cl[png_cl_order[lane]] = (uint8_t)(png_bits32(L, ip + 3 * lane) & 7);
-            wave_sync();
-            ip += 3 * hclen;
-            uint32_t cll[1] = {lane < 19 ? (uint32_t)cl[lane] : 0u};
-            Canon CC;
-            if (!canon_counts<1>(cll, CC, 7, false) || CC.count[1] + CC.count[2] + CC.count[3] + CC.count[4] + CC.count[5] + CC.count[6] + CC.count[7] == 0) {
-                err = ABUB_PNG_E_CODES;
-                break;
-            }
-            canon_sort<1>(cll, CC, scl, lane);
-            wave_sync();
-            // the code-length code's 128-entry table lives in two registers per lane (entry e: lane e & 63, register e >> 6)
-            uint32_t clt[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const uint32_t rev = __brev((uint32_t)(lane + 64 * q)) >> 25;
-                uint32_t pos;
-                const uint32_t l = canon_find<1, 7, 7>(rev, CC, pos);
-                clt[q] = l ? (l | ((uint32_t)scl[pos] << 4)) : 0u;
-            }
-            const uint32_t total = hlit + hdist;
-            uint32_t n = 0, prev = 0;
-            while (n < total) {
-                png_ensure(S, L, ip, lane);
-                uint32_t v = rfl(png_bits32(L, ip));
-                const uint32_t idx = v & 127;
-                const uint32_t ent = idx < 64 ? rdl(clt[0], idx) : rdl(clt[1], idx - 64);
-                const uint32_t l = ent & 15, sym = ent >> 4;
-                if (!l) {
-                    err = ABUB_PNG_E_CODES;
-                    break;
-                }
-                v >>= l;
-                ip += l;
-                uint32_t rep = 1, val = sym;
-                if (sym == 16) {
-                    if (!n) {
-                        err = ABUB_PNG_E_CODES;
-                        break;
-                    }
-                    rep = 3 + (v & 3);
-                    val = prev;
-                    ip += 2;
-                } else if (sym == 17) {
-                    rep = 3 + (v & 7);
-                    val = 0;
-                    ip += 3;
-                } else if (sym == 18) {
-                    rep = 11 + (v & 127);
-                    val = 0;
-                    ip += 7;
-                }
-                if (n + rep > total) {
-                    err = ABUB_PNG_E_CODES;
-                    break;
-                }
-                for (uint32_t k = lane; k < rep; k += 64) {
-                    const uint32_t q = n + k;
-                    lens[q < hlit ? q : 288 + (q - hlit)] = (uint8_t)val;
-                }
-                prev = val;
-                n += rep;
-            }
-            if (err)
-                break;
-            if (ip > S.nbits) {
-                err = ABUB_PNG_E_TRUNCATED;
-                break;
-            }
-        }
-        wave_sync();
-        // ---- tables ----
         {
-            Canon CL, CD;
-            uint32_t ll[5];
-#pragma unroll
-            for (int c = 0; c < 5; ++c) {
-                const uint32_t q = c * 64 + lane;
-                ll[c] = q < hlit ? (uint32_t)lens[q] : 0u;
-            }
-            uint32_t dl[1] = {(uint32_t)lane < hdist ? (uint32_t)lens[288 + lane] : 0u};
-            wave_sync(); // (the lengths are in registers: the literal table may now overwrite them)
-            const uint32_t eobLen = rdl(ll[4], 0); // symbol 256
-            if (!canon_counts<5>(ll, CL, LIT_ROOT, true) || !canon_counts<1>(dl, CD, DIST_ROOT, true)) {
-                err = ABUB_PNG_E_CODES;
-                break;
-            }
-            if (!eobLen) {
-                err = ABUB_PNG_E_NOEOB;
-                break;
-            }
-            canon_sort<5>(ll, CL, L.slit, lane);
-            canon_sort<1>(dl, CD, L.sdist, lane);
-            canon_store(CL, L.cl, lane);
-            canon_store(CD, L.cd, lane);
-            wave_sync();
-            canon_table<LIT_ROOT, false>(CL, L.slit, L.lit, lane);
-            canon_table<DIST_ROOT, true>(CD, L.sdist, L.dist, lane);
-            wave_sync();
+            const int rc = png_block_tables(P, L, ip, btype, lane);
+            if (rc)
+                return rc;
         }
         // ---- tokens ----
         uint32_t s = 0; // first real token start inside the window
         for (;;) {
-            png_ensure(S, L, ip, lane);
-            if (ip > S.nbits) {
-                err = ABUB_PNG_E_TRUNCATED;
-                break;
-            }
+            png_ensure(P, L, ip, lane);
+            if (ip > P.nbits)
+                return ABUB_PNG_E_TRUNCATED;
             // every lane: one token at bit offset ip + lane
             const uint32_t pos = ip + lane, w = pos >> 5, sh = pos & 31;
             const uint32_t d0 = L.in[w & (PNG_INDW - 1)], d1 = L.in[(w + 1) & (PNG_INDW - 1)], d2 = L.in[(w + 2) & (PNG_INDW - 1)];
@@ -617,11 +784,10 @@ __global__ __launch_bounds__(64) void k_png_inflate(const uint8_t *__restrict__ 
                     e = canon_slow<LIT_ROOT, false>(lo, L.cl, L.slit);
             }
             uint32_t nb = e & 15, kind = (e >> 4) & 3;
-            const uint32_t base = (e >> 10) & 0x1fffffu;
-            uint32_t olen = kind == T_LIT ? 1u : 0u, dist = 0;
+            uint32_t tok = ((e >> 10) & 255u) << 1; // a literal's byte
             if (ballot(kind == T_LEN)) {
                 const uint32_t eb = (e >> 6) & 15;
-                const uint32_t len = base + __builtin_amdgcn_ubfe(lo, nb, eb);
+                const uint32_t len = ((e >> 10) & 0x1fffffu) + __builtin_amdgcn_ubfe(lo, nb, eb);
                 const uint32_t nb2 = nb + eb;                              // <= 20
                 const uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, nb2); // the 32 bits behind the length code
                 uint32_t de = L.dist[w2 & ((1u << DIST_ROOT) - 1)];
@@ -632,8 +798,7 @@ __global__ __launch_bounds__(64) void k_png_inflate(const uint8_t *__restrict__ 
                 const uint32_t dnb = de & 15, deb = (de >> 6) & 15; // dnb + deb <= 28
                 const uint32_t dd = ((de >> 10) & 0x1fffffu) + __builtin_amdgcn_ubfe(w2, dnb, deb);
                 if (kind == T_LEN) {
-                    olen = len;
-                    dist = dd;
+                    tok = 1u | (len << 1) | (dd << 10);
                     nb = nb2 + dnb + deb;
                     if (((de >> 4) & 3) == T_BAD)
                         kind = T_BAD;
@@ -647,152 +812,129 @@ __global__ __launch_bounds__(64) void k_png_inflate(const uint8_t *__restrict__ 
                 valid |= 1ull << p;
                 p += rdl(step, p);
             } while (p < 64);
-            bool mine = (valid >> lane) & 1;
             bool eob = false;
             {
-                const uint64_t stop = ballot(mine && kind >= T_EOB); // end of block or an invalid code on the chain: what follows is not data
+                // end of block or an invalid code on the chain: what follows is not data
+                const uint64_t stop = ballot(((valid >> lane) & 1) && kind >= T_EOB);
                 if (stop) {
                     const uint32_t j = (uint32_t)__builtin_ctzll(stop);
-                    if (rdl(kind, j) == T_BAD) {
-                        err = ABUB_PNG_E_CODE;
-                        break;
-                    }
-                    valid &= (2ull << j) - 1;
-                    mine = (valid >> lane) & 1;
+                    if (rdl(kind, j) == T_BAD)
+                        return ABUB_PNG_E_CODE;
+                    valid &= (1ull << j) - 1; // (the end-of-block token itself carries no bytes)
                     p = j + rdl(nb, j);
                     eob = true;
                 }
             }
-            // ---- where the tokens' bytes go ----
-            const uint32_t ol = mine ? olen : 0u;
-            const uint32_t incl = wave_incl_scan(ol);
-            uint32_t off = incl - ol, total = rdl(incl, 63);
-            bool capped = false;
-            if (total > (uint32_t)PNG_CAP) { // (runs of long matches: keep the tokens that fit, the next iteration starts at the first one left)
-                const uint64_t keep = ballot(mine && incl <= (uint32_t)PNG_CAP);
-                p = (uint32_t)__builtin_ctzll(valid & ~keep);
-                valid = keep;
-                mine = (valid >> lane) & 1;
-                total = rdl(incl, 63 - (uint32_t)__builtin_clzll(keep));
-                eob = false;
-                capped = true;
-            }
-            if (eob || capped) {
+            if (eob)
                 ip += p;
-                s = 0;
-            } else {
+            else {
                 ip += 64;
                 s = p - 64;
             }
-            if (ip > S.nbits) {
-                err = ABUB_PNG_E_TRUNCATED;
-                break;
+            if (ip > P.nbits)
+                return ABUB_PNG_E_TRUNCATED;
+            if (valid) {
+                const int rc = sink.put(REC_TOKENS, 0, valid, tok);
+                if (rc)
+                    return rc;
             }
-            if (S.op + total > S.rawLen) {
-                err = ABUB_PNG_E_TOOMUCH;
-                break;
-            }
-            const bool isMatch = mine && kind == T_LEN;
-            const uint64_t mm = ballot(isMatch);
-            const bool nowrap = S.op_r + (uint32_t)PNG_CAP + 264 <= (uint32_t)PNG_RING; // no destination of this iteration wraps
-            const uint32_t dst = nowrap ? S.op_r + off : ring_wrap(S.op_r + off);
-            if (mine && kind == T_LIT)
-                L.win[dst] = (uint8_t)base;
-            if (mm) {
-                if (ballot(isMatch && dist > S.op + off)) {
-                    err = ABUB_PNG_E_DISTANCE;
-                    break;
-                }
-                const uint32_t m0 = rdl(off, (uint32_t)__builtin_ctzll(mm)); // output offset of the iteration's first match
-                // a match whose source ends behind m0 may read what an earlier match of this iteration writes
-                const bool dep = isMatch && (int)(off + olen) - (int)dist > (int)m0;
-                const bool own = isMatch && !dep && olen <= (uint32_t)PNG_SHORT;
-                int sidx = (int)(S.op_r + off) - (int)dist; // > -RING
-                if (sidx < 0)
-                    sidx += PNG_RING;
-                else if (sidx >= PNG_RING)
-                    sidx -= PNG_RING;
-                wave_sync();
-                const uint64_t ownm = ballot(own);
-                if (ownm) {
-                    if (nowrap && !ballot(own && sidx + PNG_SHORT > PNG_RING)) {
-                        // the common case: no byte of these copies wraps.  Every match has 3 bytes; the longer ones go on.
-                        if (own) {
-                            const uint8_t b0 = L.win[sidx], b1 = L.win[sidx + 1], b2 = L.win[sidx + 2];
-                            L.win[dst] = b0;
-                            L.win[dst + 1] = b1;
-                            L.win[dst + 2] = b2;
-                        }
-#pragma unroll
-                        for (int k = 3; k < PNG_SHORT; ++k) {
-                            if (!ballot(own && olen > (uint32_t)k))
-                                break;
-                            if (own && olen > (uint32_t)k)
-                                L.win[dst + k] = L.win[sidx + k];
-                        }
-                    } else {
-                        uint32_t b[PNG_SHORT];
-#pragma unroll
-                        for (int k = 0; k < PNG_SHORT; ++k)
-                            b[k] = (own && (uint32_t)k < olen) ? (uint32_t)L.win[ring_wrap((uint32_t)sidx + k)] : 0u;
-#pragma unroll
-                        for (int k = 0; k < PNG_SHORT; ++k)
-                            if (own && (uint32_t)k < olen)
-                                L.win[ring_wrap(ring_wrap(S.op_r + off) + k)] = (uint8_t)b[k];
-                    }
-                }
-                uint64_t rest = mm & ~ownm;
-                while (rest) {
-                    const uint32_t j = (uint32_t)__builtin_ctzll(rest);
-                    rest &= rest - 1;
-                    const uint32_t o = rdl(off, j), len = rdl(olen, j), d = rdl(dist, j);
-                    wave_sync();
-                    const uint32_t dst0 = ring_wrap(S.op_r + o);
-                    const uint32_t src0 = rdl((uint32_t)sidx, j);
-                    const float rcp = 1.0f / (float)d;
-                    for (uint32_t k0 = 0; k0 < len; k0 += 64) {
-                        const uint32_t k = k0 + lane;
-                        uint32_t r = k;
-                        if (d < len) { // overlapping: byte k repeats the pattern of d bytes
-                            const uint32_t q = (uint32_t)((float)k * rcp);
-                            int rr = (int)k - (int)(q * d);
-                            if (rr < 0)
-                                rr += (int)d;
-                            if (rr >= (int)d)
-                                rr -= (int)d;
-                            r = (uint32_t)rr;
-                        }
-                        if (k < len) {
-                            const uint8_t byte = L.win[ring_wrap(src0 + r)];
-                            L.win[ring_wrap(dst0 + k)] = byte;
-                        }
-                    }
-                }
-            }
-            png_advance(S, L, total, lane);
             if (eob)
                 break;
         }
     }
-    if (!err) {
-        wave_sync();
-        png_flush(S, L, S.op, true, lane);
-        if (S.op != S.rawLen)
-            err = ABUB_PNG_E_TOOLITTLE;
-        else {
-            ip = (ip + 7) & ~7u;
-            if (ip + 32 > S.nbits)
-                err = ABUB_PNG_E_TRUNCATED;
-            else {
-                png_ensure(S, L, ip, lane);
-                const uint32_t t = rfl(png_bits32(L, ip));
-                if (__builtin_bswap32(t) != ((S.a2 << 16) | S.a1))
-                    err = ABUB_PNG_E_ADLER;
-            }
+    // the trailer: Adler-32 of the output, big-endian, at the next byte boundary
+    ip = (ip + 7) & ~7u;
+    if (ip + 32 > P.nbits)
+        return ABUB_PNG_E_TRUNCATED;
+    png_ensure(P, L, ip, lane);
+    const uint32_t adler = __builtin_bswap32(rfl(png_bits32(L, ip)));
+    return sink.put(REC_END, adler, 0, 0);
+}
+
+template <bool TWO>
+__global__ __launch_bounds__(TWO ? 128 : 64) void k_png_inflate(const uint8_t *__restrict__ zbuf, const abub_png_frame *__restrict__ frames,
+                                                                  uint32_t rawLen, uint64_t rawStride, uint8_t *__restrict__ rawbuf,
+                                                                  int32_t *__restrict__ status, int dbg)
+{
+    __shared__ InflateLds L;
+    const int f = blockIdx.x, lane = threadIdx.x & 63;
+    const uint32_t wave = rfl(threadIdx.x >> 6);
+    if (TWO) {
+        if (threadIdx.x == 0) {
+            L.q_head = 0;
+            L.q_tail = 0;
+            L.q_abort = 0;
         }
+        __syncthreads();
     }
-    if (lane == 0)
-        status[f] = err;
+    if (status[f] != 0) // (refused by the gather kernel; the same for the whole workgroup)
+        return;
+    const abub_png_frame fr = frames[f];
+    Writer W;
+    W.z = zbuf + fr.zoff;
+    W.raw = rawbuf + (uint64_t)f * rawStride;
+    W.rawLen = rawLen;
+    W.op = W.op_r = W.fp = 0;
+    W.a1 = 1;
+    W.a2 = 0;
+    if (!TWO || wave == 0) {
+        Parser P;
+        P.z = zbuf + fr.zoff;
+        P.zlen = fr.zlen;
+        P.zpad = (fr.zlen + 15) & ~15u;
+        P.nbits = fr.zlen * 8;
+        Sink<TWO> sink = {L, &W, 0, lane, dbg};
+        int rc = png_parse<TWO>(P, L, sink, lane);
+        if (!TWO) {
+            if (lane == 0)
+                status[f] = rc;
+        } else if (rc > 0)
+            (void)sink.put(REC_ERROR, (uint32_t)rc, 0, 0); // (rc == -1: the writing wave has set the status and gone)
+        return;
+    }
+    // the writing wave
+    uint32_t tail = 0;
+    int rc = 0;
+    for (;;) {
+        uint32_t spins = 0;
+        while (q_ld(&L.q_head) == tail) {
+            if (++spins > PNG_SPINS) {
+                rc = ABUB_PNG_E_INTERNAL;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (rc)
+            break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const TokSlot &sl = L.q[tail % PNG_NSLOT];
+        const uint32_t kind = rfl(sl.kind), aux = rfl(sl.aux);
+        const uint64_t valid = ((uint64_t)rfl(sl.vhi) << 32) | rfl(sl.vlo);
+        const uint32_t tok = sl.tok[lane];
+        // (the record is in registers: the slot may be refilled while its tokens are applied)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        ++tail;
+        if (lane == 0)
+            q_st(&L.q_tail, tail);
+        const uint32_t k = kind & 3;
+        bool done = true;
+        if (k == REC_TOKENS) {
+            rc = png_apply(W, L, valid, tok, lane);
+            done = rc != 0;
+        } else if (k == REC_STORED) {
+            rc = png_apply_stored(W, L, aux, kind >> 2, lane);
+            done = rc != 0;
+        } else if (k == REC_END)
+            rc = png_apply_end(W, L, aux, lane);
+        else
+            rc = (int)aux;
+        if (done)
+            break;
+    }
+    if (lane == 0) {
+        status[f] = rc;
+        q_st(&L.q_abort, 1u);
+    }
 }
 
 // ---- unfilter: one wave per frame, lanes along x, rows in order ----------------------------------------------------
@@ -973,7 +1115,13 @@ extern "C" int abub_png_decode_dev(const uint8_t *files, size_t files_bytes, con
         return set_err(ABUB_E_INVALID, "abub_png_decode_dev: rawbuf smaller than nframes * abub_png_raw_stride(W, H)");
     hipStream_t st = (hipStream_t)stream;
     k_png_gather<<<nframes, 256, 0, st>>>(files, (uint64_t)files_bytes, frames, segs, (uint32_t)nsegs, zbuf, (uint64_t)zbuf_bytes, status);
-    k_png_inflate<<<nframes, 64, 0, st>>>(zbuf, frames, (uint32_t)((size_t)H * ((size_t)W + 1)), (uint64_t)stride, rawbuf, status);
+    // ABUB_PNG_WAVES=1: one wave parses and writes a stream; default: a parsing and a writing wave per stream
+    static const bool oneWave = [] { const char *e = getenv("ABUB_PNG_WAVES"); return e && atoi(e) == 1; }();
+    static const int dbg = [] { const char *e = getenv("ABUB_PNG_DEBUG"); return e ? atoi(e) : 0; }(); // (measurement only)
+    if (oneWave || dbg)
+        k_png_inflate<false><<<nframes, 64, 0, st>>>(zbuf, frames, (uint32_t)((size_t)H * ((size_t)W + 1)), (uint64_t)stride, rawbuf, status, dbg);
+    else
+        k_png_inflate<true><<<nframes, 128, 0, st>>>(zbuf, frames, (uint32_t)((size_t)H * ((size_t)W + 1)), (uint64_t)stride, rawbuf, status, 0);
     const int ndw = (W + 255) / 256;
 #define UNF(N)                                                                                                             \
     k_png_unfilter<N><<<nframes, 64, 0, st>>>(rawbuf, (uint64_t)stride, frames, luts, (uint32_t)nluts, W, H, out,         \

@@ -293,6 +293,7 @@ typedef struct abub_png_frame {
 #define ABUB_PNG_E_TOOLITTLE 12 /* fewer */
 #define ABUB_PNG_E_ADLER 13     /* Adler-32 of the output differs from the trailer */
 #define ABUB_PNG_E_FILTER 14    /* filter type above 4 */
+#define ABUB_PNG_E_INTERNAL 15  /* the two waves of a stream lost each other (never expected) */
 /* bytes of `rawbuf` one frame takes (its inflated, still filtered scanlines) */
 size_t abub_png_raw_stride(int W, int H);
 /* files: the uploaded file bytes (4-byte aligned, files_bytes of them); frames[nframes], segs[nsegs], luts[nluts][256];
