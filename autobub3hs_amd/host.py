@@ -157,17 +157,17 @@ class Run:
 
     def run_batched(self, ncams, outdir, run_number, frame_offset, maskdir="", ngpus=1, nthreads=16, decode_threads=16,
                     batch_mb=0, shard=(0, 1)):
-        """Every event of this run through the batched GPU pipeline (host/pipeline.cpp RunBatched): decode into pinned
-        batches, upload, detect, blocks appended to <outdir>abub3hs_<run>.txt in event order.  -> stats dict."""
+        """Every event of this run through the batched GPU pipeline (host/pipeline.cpp RunBatched): frames decoded (PNG files: on the GPU, abub_png_decode_dev; ABUB_GPU_DECODE=0: by host threads into pinned
+        batches), detect, blocks appended to <outdir>abub3hs_<run>.txt in event order.  -> stats dict."""
         L = lib()
         L.abh_run_batched.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p] + [C.c_int] * 7 + [_dp]
-        st = (C.c_double * 10)()
+        st = (C.c_double * 13)()
         rc = L.abh_run_batched(self._h, ncams, maskdir.encode(), outdir.encode(), run_number.encode(), frame_offset, ngpus,
                                nthreads, decode_threads, batch_mb, shard[0], shard[1], st)
         if rc != 0:
             raise RuntimeError(f"abh_run_batched rc={rc}: " + L.abh_last_error(self._h).decode())
         keys = ("total_s", "list_s", "decode_s", "gpu_s", "write_s", "frames", "frames_failed", "batches",
-                "events_per_batch", "gpus")
+                "events_per_batch", "gpus", "frames_gpu_decoded", "frames_host_decoded", "gpudecode_s")
         return dict(zip(keys, list(st)))
 
     def analyze(self, event, cam, maskdir=""):

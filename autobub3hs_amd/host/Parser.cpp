@@ -8,6 +8,9 @@
 
 Parser::~Parser() {}
 
+long long Parser::GetImageFileSize(std::string, std::string) { return -1; }
+long long Parser::ReadImageFile(std::string, std::string, unsigned char *, size_t) { return -1; }
+
 // keep only the events the run file knows about (reference ParseFolder/Parser.cpp:14-26)
 void Parser::VerifyEventList(std::vector<std::string> &EventList)
 {

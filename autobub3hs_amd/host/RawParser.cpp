@@ -61,6 +61,27 @@ int RawParser::GetImageInto(std::string EventID, std::string FrameName, unsigned
 #endif
 }
 
+long long RawParser::GetImageFileSize(std::string EventID, std::string FrameName)
+{
+    const std::string path = joinPath(joinPath(joinPath(RunFolder, EventID), ImageFolder), FrameName);
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode))
+        return -1;
+    return (long long)st.st_size;
+}
+
+long long RawParser::ReadImageFile(std::string EventID, std::string FrameName, unsigned char *dst, size_t cap)
+{
+    const std::string path = joinPath(joinPath(joinPath(RunFolder, EventID), ImageFolder), FrameName);
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f)
+        return -1;
+    const size_t n = fread(dst, 1, cap, f);
+    const bool more = n == cap && fgetc(f) != EOF; // (the file grew since its size was asked: not what was planned for)
+    fclose(f);
+    return more ? -1 : (long long)n;
+}
+
 void RawParser::GetFileLists(const char *EventFolder, std::vector<std::string> &FileList, const char *camera_out_name)
 {
     DIR *dir = opendir(EventFolder);

@@ -223,6 +223,47 @@ int ZipParser::GetImageInto(std::string EventID, std::string FrameName, unsigned
 #endif
 }
 
+long long ZipParser::GetImageFileSize(std::string EventID, std::string FrameName)
+{
+    BuildFileList();
+    auto ev = index->ImageLocs.find(EventID);
+    if (ev == index->ImageLocs.end())
+        return -1;
+    auto fr = ev->second.find(FrameName);
+    if (fr == ev->second.end())
+        return -1;
+    const Entry &e = index->entries[fr->second];
+    return (long long)(e.method == 0 ? e.compressedSize : e.uncompressedSize);
+}
+
+long long ZipParser::ReadImageFile(std::string EventID, std::string FrameName, unsigned char *dst, size_t cap)
+{
+    BuildFileList();
+    auto ev = index->ImageLocs.find(EventID);
+    if (ev == index->ImageLocs.end())
+        return -1;
+    auto fr = ev->second.find(FrameName);
+    if (fr == ev->second.end())
+        return -1;
+    const Entry &e = index->entries[fr->second];
+    if (e.method == 0) { // stored (what a run archive of PNGs is): straight from the archive into dst
+        if (e.compressedSize > cap)
+            return -1;
+        unsigned char lh[30];
+        if (!preadAll(fp, e.localHeaderOffset, lh, 30) || rd32(lh) != 0x04034b50u)
+            return -1;
+        const uint64_t dataOff = e.localHeaderOffset + 30 + rd16(lh + 26) + rd16(lh + 28);
+        if (e.compressedSize && !preadAll(fp, dataOff, dst, e.compressedSize))
+            return -1;
+        return (long long)e.compressedSize;
+    }
+    static thread_local std::vector<unsigned char> data; // a deflated entry: the zip layer is inflated on the host
+    if (!readEntry(fr->second, data) || data.size() > cap)
+        return -1;
+    memcpy(dst, data.data(), data.size());
+    return (long long)data.size();
+}
+
 void ZipParser::GetFileLists(const char *, std::vector<std::string> &, const char *) {} // empty upstream too (:241-244)
 
 void ZipParser::GetEventDirLists(std::vector<std::string> &EventList)

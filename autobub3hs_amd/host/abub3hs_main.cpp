@@ -336,10 +336,12 @@ int main(int argc, char **argv)
             return -6;
         }
         if (rc == 0) {
-            printf("batched detect: %d events in %d batches of <= %d on %d GPU(s), %lld frames %dx%d decoded (%lld undecodable), "
-                   "%.2f s total (list %.2f, decode %.2f, upload+GPU+host stages %.2f, write %.2f) = %.1f frames/s ingest-inclusive\n",
-                   bs.events, bs.batches, bs.eventsPerBatch, bs.gpus, bs.frames, bs.W, bs.H, bs.framesFailed, bs.total_s, bs.list_s,
-                   bs.decode_s, bs.gpu_s, bs.write_s, bs.total_s > 0 ? (bs.frames + bs.framesFailed) / bs.total_s : 0.0);
+            printf("batched detect: %d events in %d batches of <= %d on %d GPU(s), %lld frames %dx%d decoded (%lld on the GPU, %lld on "
+                   "host threads; %lld undecodable), %.2f s total (list %.2f, read/decode %.2f, upload+GPU+host stages %.2f of which "
+                   "GPU decode %.2f, write %.2f) = %.1f frames/s ingest-inclusive\n",
+                   bs.events, bs.batches, bs.eventsPerBatch, bs.gpus, bs.frames, bs.W, bs.H, bs.framesGpuDecoded, bs.framesHostDecoded,
+                   bs.framesFailed, bs.total_s, bs.list_s, bs.decode_s, bs.gpu_s, bs.gpudecode_s, bs.write_s,
+                   bs.total_s > 0 ? (bs.frames + bs.framesFailed) / bs.total_s : 0.0);
             printf("run complete.\n");
             for (Trainer *t : Trainers)
                 delete t;

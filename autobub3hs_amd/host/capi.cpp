@@ -297,7 +297,7 @@ int abh_analyze(void *r, const char *ev, int cam, const char *maskdir)
 
 // A whole run (every event of the Run's parser, cameras 0..ncams-1, the Run's trained models) through the batched
 // pipeline into <outdir>abub3hs_<run>.txt; stats: [total_s, list_s, decode_s, gpu_s, write_s, frames, failed,
-// batches, events_per_batch, gpus].  Returns 0, 1 when the batched path declines the run, -1 on errors.
+// batches, events_per_batch, gpus, frames decoded on the GPU, on host threads, gpudecode_s].  Returns 0, 1 when the batched path declines the run, -1 on errors.
 int abh_run_batched(void *r, int ncams, const char *maskdir, const char *outdir, const char *run_number, int frameOffset,
                     int ngpus, int nthreads, int decodeThreads, int batchMB, int shardRank, int shardWorld, double *statsOut)
 {
@@ -330,8 +330,9 @@ int abh_run_batched(void *r, int ncams, const char *maskdir, const char *outdir,
         if (rc != 0)
             run->error = why;
         if (statsOut) {
-            const double v[10] = {bs.total_s, bs.list_s, bs.decode_s, bs.gpu_s, bs.write_s, (double)bs.frames, (double)bs.framesFailed,
-                                  (double)bs.batches, (double)bs.eventsPerBatch, (double)bs.gpus};
+            const double v[13] = {bs.total_s, bs.list_s, bs.decode_s, bs.gpu_s, bs.write_s, (double)bs.frames, (double)bs.framesFailed,
+                                  (double)bs.batches, (double)bs.eventsPerBatch, (double)bs.gpus, (double)bs.framesGpuDecoded,
+                                  (double)bs.framesHostDecoded, bs.gpudecode_s};
             std::memcpy(statsOut, v, sizeof v);
         }
         return rc;

@@ -1172,6 +1172,62 @@ private:
     }
 };
 
+// What a host thread finds out about a PNG file before its bytes go to the GPU decoder: the IDAT chunks and, for a
+// palette image, the palette -> grey table (the same rounding as cv::imdecode's, cvlite.cpp).  false = not an 8-bit grey
+// or palette image of W x H without interlace (or not a PNG at all): such a file is decoded on the host.
+struct PngInfo {
+    std::vector<abub_png_seg> segs; // offsets relative to the file's first byte
+    bool palette = false;
+    uint8_t lut[256];
+    uint64_t zlen = 0;
+};
+static bool pngWalk(const uint8_t *buf, size_t size, int W, int H, PngInfo &out)
+{
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (size < 8 + 25 || memcmp(buf, sig, 8) != 0)
+        return false;
+    auto be32 = [&](size_t o) { return ((uint32_t)buf[o] << 24) | ((uint32_t)buf[o + 1] << 16) | ((uint32_t)buf[o + 2] << 8) | (uint32_t)buf[o + 3]; };
+    out.segs.clear();
+    out.palette = false;
+    out.zlen = 0;
+    uint8_t pal[256][3];
+    int npal = 0;
+    bool haveHdr = false, end = false;
+    size_t o = 8;
+    uint32_t w = 0, h = 0, depth = 0, ctype = 0, interlace = 1;
+    while (!end && o + 12 <= size) {
+        const uint32_t len = be32(o);
+        const uint8_t *type = buf + o + 4, *data = buf + o + 8;
+        if (o + 12 + (size_t)len > size)
+            return false;
+        if (!memcmp(type, "IHDR", 4) && len >= 13) {
+            w = be32(o + 8);
+            h = be32(o + 12);
+            depth = data[8];
+            ctype = data[9];
+            interlace = data[12];
+            haveHdr = true;
+        } else if (!memcmp(type, "PLTE", 4)) {
+            npal = std::min<int>((int)(len / 3), 256);
+            memcpy(pal, data, (size_t)npal * 3);
+        } else if (!memcmp(type, "IDAT", 4)) {
+            out.segs.push_back(abub_png_seg{(uint32_t)(o + 8), len});
+            out.zlen += len;
+        } else if (!memcmp(type, "IEND", 4))
+            end = true;
+        o += 12 + (size_t)len;
+    }
+    if (!haveHdr || (int)w != W || (int)h != H || depth != 8 || (ctype != 0 && ctype != 3) || interlace != 0 || out.segs.empty() ||
+        out.zlen >= ((uint64_t)1 << 28) || size >= ((size_t)1 << 31))
+        return false;
+    if (ctype == 3) {
+        out.palette = true;
+        for (int v = 0; v < 256; ++v)
+            out.lut[v] = v < npal ? (uint8_t)((pal[v][0] * 9797 + pal[v][1] * 19234 + pal[v][2] * 3737 + 16384) >> 15) : 0;
+    }
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // RunBatched: a run from a Parser through the batched pipeline (see runbatch.hpp).  Replaces the detect loop of the
 // reference's main program (AutoBubStart3.cpp:338-388): same per-(event, camera) analyses, same output blocks in the
@@ -1253,6 +1309,37 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
         G = std::max(1, std::min(G, want));
     }
     G = std::min(G, 512);
+    // ---- where the frames are decoded --------------------------------------------------------------------------------
+    // On the GPU (abub_png.hip) when the parser hands out the files as they are stored and the first frame is a PNG the
+    // kernels take; a host thread still reads each file and walks its chunks, and decodes the odd frame the GPU path
+    // refuses.  Otherwise host threads decode every frame (GetImageInto) as before.
+    bool devDecode = opt.gpuDecode != 0 && (W & 3) == 0 && W >= 4 && W <= 2048;
+    if (const char *e = getenv("ABUB_GPU_DECODE"))
+        devDecode = devDecode && atoi(e) != 0;
+    if (devDecode) {
+        devDecode = false;
+        for (size_t k = 0; k < lists.size() && !devDecode; ++k)
+            for (int c = 0; c < C && !devDecode; ++c)
+                if (!lists[k][c].empty()) {
+                    std::unique_ptr<Parser> p(parser->clone());
+                    const long long sz = p->GetImageFileSize(EventList[mine[k]], lists[k][c][0]);
+                    if (sz > 0 && sz < ((long long)1 << 30)) {
+                        std::vector<unsigned char> buf((size_t)sz);
+                        PngInfo info;
+                        devDecode = p->ReadImageFile(EventList[mine[k]], lists[k][c][0], buf.data(), buf.size()) == sz &&
+                                    pngWalk(buf.data(), buf.size(), W, H, info);
+                    }
+                    k = lists.size(); // (one probe decides)
+                    break;
+                }
+    }
+    if (devDecode) {
+        // the inflate kernel runs 1024 streams at a time on the chip: batches of about that many frames
+        const int perEv = std::max(1, C * Fmax);
+        const int wantG = (1024 + perEv - 1) / perEv;
+        const int capG = (int)std::max<size_t>(1, opt.batchBytes / perEvent);
+        G = std::max(G, std::min(wantG, std::min(capG, (int)mine.size())));
+    }
     const int nb = ((int)mine.size() + G - 1) / G;
     int ndev = 0;
     HIPOK(hipGetDeviceCount(&ndev));
@@ -1330,6 +1417,156 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
         out.ms = nowMs() - td;
     };
 
+    // ---- device-decode mode: a batch's FILES into one pinned buffer, with what the GPU decoder needs to know about each ----
+    struct Encoded {
+        std::vector<StackMeta> meta;
+        uint8_t *h_files = nullptr; // pinned; grown on demand by the reading thread (its worker's device is current there)
+        size_t cap = 0, bytes = 0;
+        std::vector<abub_png_frame> desc;        // the frames the GPU decodes
+        std::vector<std::pair<int, int>> where;  // (stack, frame) of desc[i]
+        std::vector<uint32_t> fileOff, fileLen;  // of desc[i] inside h_files
+        std::vector<abub_png_seg> segs;
+        std::vector<uint8_t> luts;               // 256 bytes each
+        size_t zbytes = 0;
+        // frames a host thread decoded while reading (files the GPU path does not take): pixels + (stack, frame)
+        std::vector<std::vector<uint8_t>> hostPix;
+        std::vector<std::pair<int, int>> hostWhere;
+        double ms = 0;
+        long long bad = 0;
+    };
+    auto readBatch = [&](int b, Encoded &out, int nthreads, int dev) {
+        const double td = nowMs();
+        (void)hipSetDevice(dev);
+        const int e0 = b * G, nEv = std::min(G, (int)mine.size() - e0);
+        out.meta.assign((size_t)G * C, StackMeta());
+        struct Task {
+            int s, f;
+            long long size;
+            size_t off;
+            int state; // 0 = for the GPU, 1 = decoded here, 2 = missing / undecodable
+            PngInfo info;
+            std::vector<uint8_t> pix;
+        };
+        std::vector<Task> tasks;
+        std::unique_ptr<Parser> sizer(parser->clone());
+        size_t total = 0;
+        for (int k = 0; k < G; ++k)
+            for (int c = 0; c < C; ++c) {
+                StackMeta &m = out.meta[(size_t)k * C + c];
+                if (k < nEv) {
+                    m.eventID = EventList[mine[e0 + k]];
+                    m.names = lists[e0 + k][c];
+                    m.ok.assign(m.names.size(), 0);
+                    for (int f = 0; f < (int)m.names.size(); ++f) {
+                        Task t;
+                        t.s = k * C + c;
+                        t.f = f;
+                        t.size = sizer->GetImageFileSize(m.eventID, m.names[f]);
+                        t.state = (t.size > 0 && t.size < ((long long)1 << 30)) ? 0 : 2;
+                        t.off = total;
+                        if (t.state == 0)
+                            total += ((size_t)t.size + 15) & ~(size_t)15;
+                        tasks.push_back(std::move(t));
+                    }
+                } else
+                    m.eventID = "_pad" + std::to_string(k);
+            }
+        total += 16;
+        if (total > out.cap) {
+            if (out.h_files)
+                (void)hipHostFree(out.h_files);
+            out.h_files = nullptr;
+            out.cap = total + total / 4;
+            if (hipHostMalloc((void **)&out.h_files, out.cap, hipHostMallocDefault) != hipSuccess) {
+                out.cap = 0;
+                throw std::runtime_error("RunBatched: hipHostMalloc of the file staging buffer failed");
+            }
+        }
+        out.bytes = total;
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < std::max(1, std::min<int>(nthreads, (int)tasks.size())); ++t)
+            th.emplace_back([&]() {
+                std::unique_ptr<Parser> p(parser->clone());
+                for (;;) {
+                    const size_t i = next.fetch_add(1);
+                    if (i >= tasks.size())
+                        break;
+                    Task &t = tasks[i];
+                    if (t.state != 0)
+                        continue;
+                    const StackMeta &m = out.meta[t.s];
+                    uint8_t *dst = out.h_files + t.off;
+                    long long got = -1;
+                    try {
+                        got = p->ReadImageFile(m.eventID, m.names[t.f], dst, (size_t)t.size);
+                    } catch (...) {
+                        got = -1;
+                    }
+                    if (got != t.size) {
+                        t.state = 2;
+                        continue;
+                    }
+                    if (!pngWalk(dst, (size_t)t.size, W, H, t.info)) {
+                        // not a file for the GPU decoder (BMP, 16-bit, colour, interlaced, another size): the host decoder's answer
+                        t.pix.resize(P);
+                        t.state = cv::imdecodeInto(dst, (size_t)t.size, t.pix.data(), W, H) ? 1 : 2;
+                    }
+                }
+            });
+        for (auto &t : th)
+            t.join();
+        out.desc.clear();
+        out.where.clear();
+        out.fileOff.clear();
+        out.fileLen.clear();
+        out.segs.clear();
+        out.luts.clear();
+        out.hostPix.clear();
+        out.hostWhere.clear();
+        out.bad = 0;
+        size_t zoff = 0;
+        for (Task &t : tasks) {
+            if (t.state == 2) {
+                ++out.bad;
+                continue;
+            }
+            if (t.state == 1) {
+                out.hostPix.push_back(std::move(t.pix));
+                out.hostWhere.emplace_back(t.s, t.f);
+                continue;
+            }
+            abub_png_frame d;
+            d.seg_begin = (uint32_t)out.segs.size();
+            d.seg_count = (uint32_t)t.info.segs.size();
+            d.zoff = (uint32_t)zoff;
+            d.zlen = (uint32_t)t.info.zlen;
+            d.lut = 0xffffffffu;
+            d.reserved = 0;
+            d.dst = ((uint64_t)t.s * Fmax + t.f) * P;
+            if (t.info.palette) { // (the frames of a run share their palette: look for the table among those already kept)
+                size_t nl = out.luts.size() / 256, l = 0;
+                for (; l < nl; ++l)
+                    if (!memcmp(&out.luts[l * 256], t.info.lut, 256))
+                        break;
+                if (l == nl)
+                    out.luts.insert(out.luts.end(), t.info.lut, t.info.lut + 256);
+                d.lut = (uint32_t)l;
+            }
+            for (const abub_png_seg &sg : t.info.segs)
+                out.segs.push_back(abub_png_seg{(uint32_t)(t.off + sg.off), sg.len});
+            zoff += (((size_t)d.zlen + 15) & ~(size_t)15) + 16;
+            out.desc.push_back(d);
+            out.where.emplace_back(t.s, t.f);
+            out.fileOff.push_back((uint32_t)t.off);
+            out.fileLen.push_back((uint32_t)t.size);
+        }
+        out.zbytes = zoff + 16;
+        if (out.bytes >= ((size_t)1 << 32) || out.zbytes >= ((size_t)1 << 32))
+            throw std::runtime_error("RunBatched: a batch of more than 4 GB of files (lower the batch size)");
+        out.ms = nowMs() - td;
+    };
+
     auto writeBatch = [&](RunPipeline &pipe, int b) {
         const int e0 = b * G, nEv = std::min(G, (int)mine.size() - e0);
         for (int k = 0; k < nEv; ++k) {
@@ -1366,17 +1603,37 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
         // The look-ahead decode thread writes decd[] and reads nthr: both live OUTSIDE the try block, so that they outlive
         // it on every failure path (the thread is joined below, after the catch).
         Decoded decd[2];
+        Encoded encd[2]; // device-decode mode
+        // device-decode mode: the uploaded files, the decoder's scratch, its descriptors (grown on demand)
+        uint8_t *d_files = nullptr, *d_z = nullptr, *d_raw = nullptr, *d_luts = nullptr;
+        abub_png_frame *d_desc = nullptr;
+        abub_png_seg *d_segs = nullptr;
+        int32_t *d_status = nullptr, *h_status = nullptr;
+        size_t capFiles = 0, capZ = 0, capRaw = 0, capLuts = 0, capDesc = 0, capSegs = 0, capStatus = 0;
         const int nthr = std::max(1, ndec / ngpus);
         std::thread dec;
+        std::exception_ptr decErr[2];
         try {
             const int dev = (opt.firstDevice + g) % ndev;
             HIPOK(hipSetDevice(dev));
             const size_t slabBytes = (size_t)G * perEvent;
             const int nslots = g + ngpus < nb ? 2 : 1; // a worker with a single batch needs no second buffer
             for (int k = 0; k < nslots; ++k) {
-                HIPOK(hipHostMalloc((void **)&h_slab[k], slabBytes, hipHostMallocDefault));
+                if (!devDecode) // (device-decode mode uploads files, not frames)
+                    HIPOK(hipHostMalloc((void **)&h_slab[k], slabBytes, hipHostMallocDefault));
                 HIPOK(hipMalloc((void **)&d_slab[k], slabBytes));
             }
+            auto grow = [&](void **ptr, size_t &cap, size_t need) {
+                if (need <= cap)
+                    return;
+                if (*ptr)
+                    HIPOK(hipFree(*ptr));
+                *ptr = nullptr;
+                cap = need + need / 4 + 256;
+                HIPOK(hipMalloc(ptr, cap));
+            };
+            if (devDecode)
+                HIPOK(hipHostMalloc((void **)&h_status, (size_t)G * C * Fmax * sizeof(int32_t) + 64, hipHostMallocDefault));
             HIPOK(hipMalloc((void **)&d_model, 3 * (size_t)C * P)); // mu | sigma | sigma6
             uint8_t *d_mu = d_model, *d_sigma = d_model + (size_t)C * P, *d_s6 = d_model + 2 * (size_t)C * P;
             HIPOK(hipStreamCreateWithFlags(&copyStream, hipStreamNonBlocking));
@@ -1391,21 +1648,101 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
             RunPipeline pipe(dev, W, H, Fmax, G, C, tss.data(), std::max(1, opt.hostThreads), opt.maskDir.c_str());
             pipe.d_sigmaRaw = d_sigma;
             int slot = 0;
+            // (an exception of the look-ahead thread -- a failed allocation, a throwing parser -- is carried over and re-thrown here)
+            auto startDecode = [&](int bb, int sl) {
+                decErr[sl] = nullptr;
+                dec = std::thread([&, bb, sl, dev]() { // (dev by value: it lives inside the try block)
+                    try {
+                        if (devDecode)
+                            readBatch(bb, encd[sl], nthr, dev);
+                        else
+                            decodeBatch(bb, h_slab[sl], decd[sl], nthr);
+                    } catch (...) {
+                        decErr[sl] = std::current_exception();
+                    }
+                });
+            };
             if (g < nb)
-                dec = std::thread([&, slot]() { decodeBatch(g, h_slab[slot], decd[slot], nthr); });
+                startDecode(g, slot);
             for (int b = g; b < nb; b += ngpus) {
                 dec.join();
+                if (decErr[slot])
+                    std::rethrow_exception(decErr[slot]);
                 const int bn = b + ngpus;
-                if (bn < nb) {
-                    const int ns = slot ^ 1;
-                    dec = std::thread([&, bn, ns]() { decodeBatch(bn, h_slab[ns], decd[ns], nthr); });
-                }
+                if (bn < nb)
+                    startDecode(bn, slot ^ 1);
                 const int nEv = std::min(G, (int)mine.size() - b * G);
                 const double tg = nowMs();
-                HIPOK(hipMemcpyAsync(d_slab[slot], h_slab[slot], (size_t)nEv * perEvent, hipMemcpyHostToDevice, copyStream));
-                const double dms = decd[slot].ms;
-                const long long good = decd[slot].ok, bad = decd[slot].bad;
-                pipe.setStackMeta(std::move(decd[slot].meta));
+                double dms = 0, pngms = 0;
+                long long good = 0, bad = 0, onGpu = 0, onHost = 0;
+                if (!devDecode) {
+                    HIPOK(hipMemcpyAsync(d_slab[slot], h_slab[slot], (size_t)nEv * perEvent, hipMemcpyHostToDevice, copyStream));
+                    dms = decd[slot].ms;
+                    good = decd[slot].ok;
+                    bad = decd[slot].bad;
+                    onHost = good;
+                    pipe.setStackMeta(std::move(decd[slot].meta));
+                } else {
+                    Encoded &E = encd[slot];
+                    const int nf = (int)E.desc.size();
+                    // frames nobody decodes (missing, undecodable) stay zero: results never use them, but dense garbage would
+                    // cost the trigger search's kernels time that varies from run to run
+                    HIPOK(hipMemsetAsync(d_slab[slot], 0, (size_t)nEv * perEvent, copyStream));
+                    const double tp = nowMs();
+                    std::vector<uint8_t> okGpu((size_t)nf, 0);
+                    if (nf) {
+                        const size_t stride = abub_png_raw_stride(W, H);
+                        grow((void **)&d_files, capFiles, E.bytes);
+                        grow((void **)&d_z, capZ, E.zbytes);
+                        grow((void **)&d_raw, capRaw, (size_t)nf * stride);
+                        grow((void **)&d_desc, capDesc, (size_t)nf * sizeof(abub_png_frame));
+                        grow((void **)&d_segs, capSegs, E.segs.size() * sizeof(abub_png_seg) + 8);
+                        grow((void **)&d_luts, capLuts, E.luts.size() + 256);
+                        grow((void **)&d_status, capStatus, (size_t)nf * sizeof(int32_t));
+                        HIPOK(hipMemcpyAsync(d_files, E.h_files, E.bytes, hipMemcpyHostToDevice, copyStream));
+                        HIPOK(hipMemcpyAsync(d_desc, E.desc.data(), (size_t)nf * sizeof(abub_png_frame), hipMemcpyHostToDevice, copyStream));
+                        HIPOK(hipMemcpyAsync(d_segs, E.segs.data(), E.segs.size() * sizeof(abub_png_seg), hipMemcpyHostToDevice, copyStream));
+                        if (!E.luts.empty())
+                            HIPOK(hipMemcpyAsync(d_luts, E.luts.data(), E.luts.size(), hipMemcpyHostToDevice, copyStream));
+                        check(abub_png_decode_dev(d_files, E.bytes, d_desc, nf, d_segs, (int)E.segs.size(), d_luts, (int)(E.luts.size() / 256), W,
+                                                  H, d_z, capZ, d_raw, capRaw, d_slab[slot], (size_t)nEv * perEvent, d_status, copyStream),
+                              "abub_png_decode_dev");
+                        HIPOK(hipMemcpyAsync(h_status, d_status, (size_t)nf * sizeof(int32_t), hipMemcpyDeviceToHost, copyStream));
+                        HIPOK(hipStreamSynchronize(copyStream));
+                        for (int i = 0; i < nf; ++i)
+                            okGpu[i] = h_status[i] == 0;
+                    }
+                    // a frame the kernels refused: the host decoder's answer (the same image, or the same failure)
+                    std::vector<uint8_t> pix;
+                    for (int i = 0; i < nf; ++i) {
+                        StackMeta &m = E.meta[E.where[i].first];
+                        if (okGpu[i]) {
+                            m.ok[E.where[i].second] = 1;
+                            ++onGpu;
+                            continue;
+                        }
+                        pix.resize(P);
+                        if (cv::imdecodeInto(E.h_files + E.fileOff[i], E.fileLen[i], pix.data(), W, H)) {
+                            HIPOK(hipMemcpy(d_slab[slot] + E.desc[i].dst, pix.data(), P, hipMemcpyHostToDevice));
+                            m.ok[E.where[i].second] = 1;
+                            ++onHost;
+                        } else {
+                            HIPOK(hipMemset(d_slab[slot] + E.desc[i].dst, 0, P)); // (a refused frame may be half written)
+                            ++E.bad;
+                        }
+                    }
+                    for (size_t i = 0; i < E.hostPix.size(); ++i) {
+                        const size_t at = ((size_t)E.hostWhere[i].first * Fmax + E.hostWhere[i].second) * P;
+                        HIPOK(hipMemcpy(d_slab[slot] + at, E.hostPix[i].data(), P, hipMemcpyHostToDevice));
+                        E.meta[E.hostWhere[i].first].ok[E.hostWhere[i].second] = 1;
+                        ++onHost;
+                    }
+                    pngms = nowMs() - tp;
+                    dms = E.ms;
+                    good = onGpu + onHost;
+                    bad = E.bad;
+                    pipe.setStackMeta(std::move(E.meta));
+                }
                 if (const char *tf = getenv("ABUB_TEST_FAIL_BATCH")) // test hook: a batch fails while the next one decodes
                     if (atoi(tf) == b)
                         throw std::runtime_error("injected failure of batch " + std::to_string(b) + " (ABUB_TEST_FAIL_BATCH)");
@@ -1430,6 +1767,9 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
                     st.write_s += wms * 1e-3;
                     st.frames += good;
                     st.framesFailed += bad;
+                    st.framesGpuDecoded += onGpu;
+                    st.framesHostDecoded += onHost;
+                    st.gpudecode_s += pngms * 1e-3;
                 }
                 slot ^= 1;
             }
@@ -1453,6 +1793,14 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
         }
         if (d_model)
             (void)hipFree(d_model);
+        for (void *q : {(void *)d_files, (void *)d_z, (void *)d_raw, (void *)d_luts, (void *)d_desc, (void *)d_segs, (void *)d_status})
+            if (q)
+                (void)hipFree(q);
+        if (h_status)
+            (void)hipHostFree(h_status);
+        for (Encoded &E : encd)
+            if (E.h_files)
+                (void)hipHostFree(E.h_files);
     };
     std::vector<std::thread> th;
     for (int g = 1; g < ngpus; ++g)

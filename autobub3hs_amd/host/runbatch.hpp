@@ -23,11 +23,16 @@ struct BatchedRunOptions {
     size_t batchBytes = (size_t)3 << 30; // frame bytes per batch; each worker holds two pinned and two HBM slabs of it
     int shardRank = 0, shardWorld = 1;   // this process takes events with index % shardWorld == shardRank
     std::string maskDir;
+    int gpuDecode = -1;             // PNG frames decoded on the GPU (abub_png_decode_dev): 1 on, 0 off (host threads decode),
+                                    // -1 = on where the parser hands out the files and the frames are 8-bit grey / palette
+                                    // PNGs of a width the kernels take (ABUB_GPU_DECODE=0/1 overrides)
 };
 
 struct BatchedRunStats {
     double list_s = 0, decode_s = 0, gpu_s = 0, write_s = 0, total_s = 0; // decode/gpu: summed over batches (they overlap)
     long long frames = 0, framesFailed = 0;
+    long long framesGpuDecoded = 0, framesHostDecoded = 0; // of `frames`: by abub_png_decode_dev / by a host thread
+    double gpudecode_s = 0;                                // upload of the files + the decode kernels, summed over batches
     int events = 0, batches = 0, eventsPerBatch = 0, W = 0, H = 0, Fmax = 0, gpus = 0;
 };
 

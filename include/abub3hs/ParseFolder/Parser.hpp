@@ -32,6 +32,11 @@ public:
     // ingestion path needs (no cv::Mat, no copy).  1 = ok; anything else (missing, undecodable, another size) = not written.
     // The base implementation goes through GetImage(); RawParser / ZipParser decode in place with thread-local scratch.
     virtual int GetImageInto(std::string EventID, std::string FrameName, unsigned char *dst, int W, int H);
+    // not in the reference either: the frame's FILE as it is stored (still a PNG / BMP), for the batched path's decoder on
+    // the GPU (abub_png_decode_dev).  GetImageFileSize: its size in bytes, or -1 where the parser cannot hand files out (the
+    // caller then uses GetImageInto); ReadImageFile: the bytes into dst (room for cap), returns their count or -1.
+    virtual long long GetImageFileSize(std::string EventID, std::string FrameName);
+    virtual long long ReadImageFile(std::string EventID, std::string FrameName, unsigned char *dst, size_t cap);
     virtual void GetEventDirLists(std::vector<std::string> &EventList) = 0;
     virtual void GetFileLists(const char *EventFolder, std::vector<std::string> &FileList, const char *camera_out_name) = 0;
     // frame names of camera `camera` in event `EventID`, sorted lexicographically (RawParser.cpp:155)

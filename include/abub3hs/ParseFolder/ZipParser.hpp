@@ -35,6 +35,8 @@ public:
 
     int GetImage(std::string EventID, std::string FrameName, cv::Mat &Image) override;
     int GetImageInto(std::string EventID, std::string FrameName, unsigned char *dst, int W, int H) override;
+    long long GetImageFileSize(std::string EventID, std::string FrameName) override;
+    long long ReadImageFile(std::string EventID, std::string FrameName, unsigned char *dst, size_t cap) override;
     void GetEventDirLists(std::vector<std::string> &EventList) override;
     void GetFileLists(const char *EventFolder, std::vector<std::string> &FileList, const char *camera_out_name) override;
     void ParseAndSortFramesInFolder(std::string EventID, int camera, std::vector<std::string> &Contents) override;

@@ -216,6 +216,47 @@ def test_batched_run_survives_a_failing_batch(tmp_path, monkeypatch):
     assert a == b and len(a.splitlines()) >= 8
 
 
+@pytest.mark.gpu
+def test_batched_run_with_frames_decoded_on_the_gpu(tmp_path, monkeypatch):
+    """The batched run decodes PNG frames on the GPU (abub_png_decode_dev) when the parser hands out the files; host threads
+    then only read them.  Same text as with host decode, from a directory, a stored and a deflated archive; a 16-bit PNG, a
+    truncated file, an empty file and a frame of another size among the frames take the host decoder's answer."""
+    W, H, F = 320, 128, 20
+    rd, frames = make_run_dir(str(tmp_path), W=W, H=H, F=F, nev=6, ncams=2)
+    d3 = os.path.join(rd, "3", "Images")
+    Image.fromarray((frames[(3, 0, "cam0_image37.png")].astype(np.uint16) << 8)).save(os.path.join(d3, "cam0_image37.png"))  # 16-bit grey
+    data = open(os.path.join(d3, "cam1_image40.png"), "rb").read()
+    open(os.path.join(d3, "cam1_image40.png"), "wb").write(data[:len(data) // 2])  # truncated
+    open(os.path.join(rd, "4", "Images", "cam0_image33.png"), "wb").close()  # empty
+    Image.fromarray(np.zeros((H, W + 4), np.uint8)).save(os.path.join(rd, "4", "Images", "cam1_image35.png"))  # another size
+    Image.fromarray(frames[(5, 0, "cam0_image38.png")]).convert("P").save(os.path.join(rd, "5", "Images", "cam0_image38.png"))  # palette
+    zs, zd = os.path.join(str(tmp_path), "stored.zip"), os.path.join(str(tmp_path), "deflated.zip")
+    zip_run(rd, zs, zipfile.ZIP_STORED)
+    zip_run(rd, zd, zipfile.ZIP_DEFLATED)
+
+    def go(kind, src, tag, gpu):
+        monkeypatch.setenv("ABUB_GPU_DECODE", "1" if gpu else "0")
+        outdir = os.path.join(str(tmp_path), tag)
+        os.makedirs(outdir, exist_ok=True)
+        run = host.Run(kind, src, "Images")
+        try:
+            for c in range(2):
+                assert run.train(c, shape=(H, W))[0] == 0
+            st = run.run_batched(2, outdir + "/", "r", 30, nthreads=4, decode_threads=4, batch_mb=2)
+        finally:
+            run.close()
+        return st, open(os.path.join(outdir, "abub3hs_r.txt")).read()
+
+    st0, ref = go("raw", rd + "/", "host", False)
+    assert st0["frames_gpu_decoded"] == 0 and st0["frames_failed"] == 3
+    for kind, src, tag in (("raw", rd + "/", "gpu_raw"), ("zip", zs, "gpu_stored"), ("zip", zd, "gpu_deflated")):
+        st, text = go(kind, src, tag, True)
+        assert text == ref, tag
+        assert st["frames_failed"] == 3 and st["frames_host_decoded"] == 1, (tag, st)  # the 16-bit frame
+        assert st["frames_gpu_decoded"] == 6 * 2 * F - 4, (tag, st)
+    assert len(ref.splitlines()) >= 12
+
+
 @pytest.mark.parametrize("ext", ["png", "bmp"])
 def test_imwrite_round_trip(tmp_path, ext):
     """Debug image write-out (AnalyzerUnit.cpp:237, L3Localizer.cpp:236-257): what cvlite writes, Pillow and cvlite's
