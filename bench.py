@@ -572,13 +572,16 @@ def ingest_inclusive(args, slab, pipe, E, C, F, W, H):
         nrows = sum(1 for _ in open(os.path.join(tmp, f"abub3hs_{run_id}.txt")))
         return {
             "frames_per_s": nev * C * F / t_detect, "frames": nev * C * F, "events": nev,
-            "source": f"zip archive on local disk, {zbytes / 1e6:.0f} MB of 8-bit grey PNG (compress_level 1), ZipParser + own PNG decoder",
+            "source": f"zip archive on local disk, {zbytes / 1e6:.0f} MB of 8-bit grey PNG (compress_level 1), ZipParser; frames decoded "
+                      "on the GPU (abub_png_decode_dev) unless ABUB_GPU_DECODE=0 (then: own PNG decoder on host threads)",
+            "frames_decoded_on_gpu": int(stats["frames_gpu_decoded"]), "frames_decoded_on_host": int(stats["frames_host_decoded"]),
             "decode_threads": ndec, "host_threads": nthr, "cores_available": ncore, "seconds": {"detect_total": t_detect, "list": stats["list_s"], "decode": stats["decode_s"],
-                                                "upload_gpu_host_stages": stats["gpu_s"], "write": stats["write_s"],
+                                                "upload_gpu_host_stages": stats["gpu_s"], "gpu_decode_of_that": stats["gpudecode_s"], "write": stats["write_s"],
                                                 "training_from_archive": t_train, "making_the_archive": t_make},
             "frames_per_s_decode_only": nev * C * F / max(stats["decode_s"], 1e-9),
             "batches": int(stats["batches"]), "output_rows": nrows,
-            "note": "detect_total = list + decode (overlapped with the GPU from the second batch on) + upload + detect + write; "
+            "note": "detect_total = list + decode (reading the files, or reading + host decode; overlapped with the GPU from the second "
+                    "batch on) + upload + GPU decode + detect + write; "
                     "training (2 frames per event and camera, decoded separately) is outside the figure like in the resident run",
         }
     finally:

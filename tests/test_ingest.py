@@ -255,6 +255,23 @@ def test_batched_run_with_frames_decoded_on_the_gpu(tmp_path, monkeypatch):
         assert st["frames_failed"] == 3 and st["frames_host_decoded"] == 1, (tag, st)  # the 16-bit frame
         assert st["frames_gpu_decoded"] == 6 * 2 * F - 4, (tag, st)
     assert len(ref.splitlines()) >= 12
+    # batches shared between the GPU (the first two events of each) and the host threads (the third)
+    monkeypatch.setenv("ABUB_GPU_DECODE_EVENTS", "2")
+    monkeypatch.setenv("ABUB_HOST_DECODE_EVENTS", "1")
+    outdir = os.path.join(str(tmp_path), "hybrid")
+    os.makedirs(outdir)
+    monkeypatch.setenv("ABUB_GPU_DECODE", "1")
+    run = host.Run("zip", zs, "Images")
+    try:
+        for c in range(2):
+            assert run.train(c, shape=(H, W))[0] == 0
+        st = run.run_batched(2, outdir + "/", "r", 30, nthreads=4, decode_threads=4, batch_mb=64)
+    finally:
+        run.close()
+    assert open(os.path.join(outdir, "abub3hs_r.txt")).read() == ref
+    assert st["events_per_batch"] == 3 and st["batches"] == 3, st  # (7 event directories: 0..5 and the frame-less 9)
+    assert st["frames_failed"] == 3 and st["frames_gpu_decoded"] + st["frames_host_decoded"] == 6 * 2 * F - 3, st
+    assert st["frames_host_decoded"] >= 2 * 2 * F - 3, st
 
 
 @pytest.mark.parametrize("ext", ["png", "bmp"])
