@@ -409,7 +409,7 @@ __device__ __forceinline__ void png_advance(Writer &S, InflateLds &L, uint32_t t
 
 // ---- the writing side: tokens -> the history ring ----
 // One window's tokens (valid = which bit offsets hold one; tok as in TokSlot).  Returns a status.
-__device__ __forceinline__ int png_apply(Writer &S, InflateLds &L, uint64_t valid, uint32_t tok, int lane)
+__device__ __forceinline__ int png_apply(Writer &S, InflateLds &L, uint64_t valid, uint32_t tok, int lane, int dbg = 0)
 {
     const bool mine = (valid >> lane) & 1;
     const bool isM = tok & 1;
@@ -430,9 +430,9 @@ __device__ __forceinline__ int png_apply(Writer &S, InflateLds &L, uint64_t vali
         const uint64_t mm = ballot(isMatch);
         const bool nowrap = S.op_r + (uint32_t)PNG_CAP + 264 <= (uint32_t)PNG_RING; // no destination of this pass wraps
         const uint32_t dst = nowrap ? S.op_r + off : ring_wrap(S.op_r + off);
-        if (sel && !isM)
+        if (sel && !isM && dbg != 3)
             L.win[dst] = (uint8_t)lit;
-        if (mm) {
+        if (mm && dbg < 2) {
             if (ballot(isMatch && dist > S.op + off))
                 return ABUB_PNG_E_DISTANCE;
             const uint32_t m0 = rdl(off, (uint32_t)__builtin_ctzll(mm)); // output offset of the pass's first match
@@ -575,11 +575,11 @@ struct Sink {
             if (dbg == 1)
                 return 0;
             if (k == REC_TOKENS)
-                return png_apply(*W, L, valid, tok, lane);
+                return png_apply(*W, L, valid, tok, lane, dbg);
             if (k == REC_STORED)
                 return png_apply_stored(*W, L, aux, kind >> 2, lane);
             if (k == REC_END)
-                return png_apply_end(*W, L, aux, lane);
+                return dbg ? 0 : png_apply_end(*W, L, aux, lane);
             return (int)aux;
         }
         uint32_t spins = 0;
