@@ -21,11 +21,12 @@
 // refuse (status != 0) is left to the caller, which decodes it on the host (the result is the same image or the same
 // failure: both follow RFC 1950/1951 and the PNG specification).
 #include "abub_dev.hpp"
+#include <stddef.h>
 
 namespace {
 
 constexpr int PNG_WIN = 32768;   // deflate history
-constexpr int PNG_CAP = 1024;    // output bytes one iteration may produce (ring = history + this)
+constexpr int PNG_CAP = 512;     // output bytes one pass over a record's tokens may produce (ring = history + this)
 constexpr int PNG_RING = PNG_WIN + PNG_CAP;
 constexpr int PNG_INDW = 128;    // input ring in dwords (512 B, refilled 256 B at a time, one refill prefetched in registers)
 constexpr int PNG_NSLOT = 2;     // token records in flight between the parsing and the writing wave
@@ -230,10 +231,11 @@ __device__ const uint8_t png_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 1
 // what the parsing wave hands to the writing wave
 enum { REC_TOKENS = 0, REC_STORED = 1, REC_END = 2, REC_ERROR = 3 };
 struct TokSlot {
-    uint32_t tok[64]; // per bit offset of the window: literal = byte << 1; match = 1 | length << 1 | distance << 10
-    uint32_t vlo, vhi; // which of them are tokens of the stream
-    uint32_t kind;     // REC_* (REC_STORED: | length << 2)
-    uint32_t aux;      // REC_STORED: byte offset of the data in the stream; REC_END: the stream's Adler-32; REC_ERROR: status
+    uint32_t tok[2][64]; // two windows of 64 bit offsets: literal = byte << 1; match = 1 | length << 1 | distance << 10
+    uint32_t v[4];       // which of them are tokens of the stream (window 0: v[0] | v[1] << 32, window 1: v[2], v[3])
+    uint32_t kind;       // REC_* (REC_STORED: | length << 2)
+    uint32_t aux;        // REC_STORED: byte offset of the data in the stream; REC_END: the stream's Adler-32; REC_ERROR: status
+    uint32_t pad[2];
 };
 struct InflateLds {
     alignas(16) uint8_t win[PNG_RING];
@@ -245,12 +247,14 @@ struct InflateLds {
     CanonLds cl, cd;
     TokSlot q[PNG_NSLOT];
     uint32_t q_head, q_tail, q_abort, q_pad;
+    uint8_t sink[16]; // where the byte stores of lanes that have nothing to store go (straight-line code, no exec masks)
 };
 // scratch of the header parse inside the (then dead) literal table: lens[320] | cl[32] | scl[32] (u16)
 __device__ __forceinline__ uint8_t *hdr_lens(InflateLds &L) { return (uint8_t *)L.lit; }
 __device__ __forceinline__ uint8_t *hdr_cl(InflateLds &L) { return (uint8_t *)L.lit + 320; }
 __device__ __forceinline__ uint16_t *hdr_scl(InflateLds &L) { return (uint16_t *)((uint8_t *)L.lit + 352); }
-static_assert(sizeof(InflateLds) <= 40960, "four inflate waves per CU");
+static_assert(sizeof(InflateLds) <= 40960, "four inflate streams per CU");
+static_assert(offsetof(InflateLds, win) == 0, "png_apply indexes the LDS block from the ring's first byte");
 
 // ---- gather: IDAT chunks -> one zlib stream per frame ------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_png_gather(const uint8_t *__restrict__ files, uint64_t files_bytes,
@@ -346,10 +350,10 @@ __device__ __forceinline__ void png_in_start(Parser &P, InflateLds &L, uint32_t 
     P.pf = png_load4(P, P.in_hi + 4 * lane);
     png_refill(P, L, lane);
 }
-// the ring covers every dword a window read at bit positions ip .. ip + 63 touches (and 32-bit peeks at ip)
+// the ring covers every dword the window reads at bit positions ip .. ip + 127 touch (and 32-bit peeks at ip)
 __device__ __forceinline__ void png_ensure(Parser &P, InflateLds &L, uint32_t ip, int lane)
 {
-    const uint32_t need = ((ip + 127) >> 5) * 4 + 12;
+    const uint32_t need = ((ip + 191) >> 5) * 4 + 12;
     while (need > P.in_hi)
         png_refill(P, L, lane);
 }
@@ -408,124 +412,185 @@ __device__ __forceinline__ void png_advance(Writer &S, InflateLds &L, uint32_t t
 }
 
 // ---- the writing side: tokens -> the history ring ----
-// One window's tokens (valid = which bit offsets hold one; tok as in TokSlot).  Returns a status.
-__device__ __forceinline__ int png_apply(Writer &S, InflateLds &L, uint64_t valid, uint32_t tok, int lane, int dbg = 0)
+// One record's tokens: two windows (valid[r] = which bit offsets of window r hold a token; tok as in TokSlot).  The two
+// windows go through every step side by side: their dependent instruction chains interleave.  Returns a status.
+__device__ __forceinline__ int png_apply(Writer &S, InflateLds &L, const uint64_t (&valid)[2], const uint32_t (&tok)[2], int lane, int dbg = 0)
 {
-    const bool mine = (valid >> lane) & 1;
-    const bool isM = tok & 1;
-    const uint32_t olen = mine ? (isM ? (tok >> 1) & 511u : 1u) : 0u;
-    const uint32_t dist = tok >> 10, lit = (tok >> 1) & 255u;
-    const uint32_t incl = wave_incl_scan(olen);
-    uint64_t todo = valid;
+    // the ring is the first member of the LDS block: byte stores go through one pointer, the sink (where lanes without a
+    // byte to store write) is an index like any other
+    uint8_t *const win = reinterpret_cast<uint8_t *>(&L);
+    constexpr uint32_t SINK = (uint32_t)offsetof(InflateLds, sink);
+    bool isM[2];
+    uint32_t olen[2], dist[2], lit[2], incl[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const bool mine = (valid[r] >> lane) & 1;
+        isM[r] = tok[r] & 1;
+        olen[r] = mine ? (isM[r] ? (tok[r] >> 1) & 511u : 1u) : 0u;
+        dist[r] = tok[r] >> 10;
+        lit[r] = (tok[r] >> 1) & 255u;
+    }
+    incl[0] = wave_incl_scan(olen[0]);
+    incl[1] = wave_incl_scan(olen[1]);
+    incl[1] += rdl(incl[0], 63);
+    uint64_t todo[2] = {valid[0], valid[1]};
     uint32_t consumed = 0;
     do {
-        // the tokens of this pass: the whole window unless it carries more than PNG_CAP bytes (runs of long matches)
-        const bool sel = ((todo >> lane) & 1) && incl - consumed <= (uint32_t)PNG_CAP;
-        const uint64_t selm = ballot(sel);
-        const uint32_t total = rdl(incl, 63 - (uint32_t)__builtin_clzll(selm)) - consumed;
-        const uint32_t off = incl - olen - consumed;
+        // the tokens of this pass: the whole record unless it carries more than PNG_CAP bytes (runs of long matches)
+        bool sel[2];
+        uint64_t selm[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            sel[r] = ((todo[r] >> lane) & 1) && incl[r] - consumed <= (uint32_t)PNG_CAP;
+            selm[r] = ballot(sel[r]);
+        }
+        const uint32_t total = (selm[1] ? rdl(incl[1], 63 - (uint32_t)__builtin_clzll(selm[1]))
+                                        : rdl(incl[0], 63 - (uint32_t)__builtin_clzll(selm[0]))) - consumed;
         if (S.op + total > S.rawLen)
             return ABUB_PNG_E_TOOMUCH;
-        const bool isMatch = sel && isM;
-        const uint64_t mm = ballot(isMatch);
         const bool nowrap = S.op_r + (uint32_t)PNG_CAP + 264 <= (uint32_t)PNG_RING; // no destination of this pass wraps
-        const uint32_t dst = nowrap ? S.op_r + off : ring_wrap(S.op_r + off);
-        if (sel && !isM && dbg != 3)
-            L.win[dst] = (uint8_t)lit;
-        if (mm && dbg < 2) {
-            if (ballot(isMatch && dist > S.op + off))
+        uint32_t off[2], dst[2];
+        bool isMatch[2];
+        uint64_t mm[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            off[r] = incl[r] - olen[r] - consumed;
+            dst[r] = nowrap ? S.op_r + off[r] : ring_wrap(S.op_r + off[r]);
+            isMatch[r] = sel[r] && isM[r];
+            mm[r] = ballot(isMatch[r]);
+        }
+        if (dbg != 3) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                win[(sel[r] && !isM[r]) ? dst[r] : SINK] = (uint8_t)lit[r];
+        }
+        if ((mm[0] | mm[1]) && dbg < 2) {
+            if (ballot(isMatch[0] && dist[0] > S.op + off[0]) | ballot(isMatch[1] && dist[1] > S.op + off[1]))
                 return ABUB_PNG_E_DISTANCE;
-            const uint32_t m0 = rdl(off, (uint32_t)__builtin_ctzll(mm)); // output offset of the pass's first match
-            // a match whose source ends behind m0 may read what an earlier match of this pass writes
-            const bool dep = isMatch && (int)(off + olen) - (int)dist > (int)m0;
-            const bool own = isMatch && !dep && olen <= (uint32_t)PNG_SHORT;
-            int sidx = (int)(S.op_r + off) - (int)dist; // > -RING
-            if (sidx < 0)
-                sidx += PNG_RING;
-            else if (sidx >= PNG_RING)
-                sidx -= PNG_RING;
+            // output offset of the pass's first match: a match whose source ends behind it may read what an earlier match of
+            // this pass writes
+            const uint32_t m0 = mm[0] ? rdl(off[0], (uint32_t)__builtin_ctzll(mm[0])) : rdl(off[1], (uint32_t)__builtin_ctzll(mm[1]));
+            bool own[2];
+            int sidx[2];
+            uint64_t ownm[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const bool dep = isMatch[r] && (int)(off[r] + olen[r]) - (int)dist[r] > (int)m0;
+                own[r] = isMatch[r] && !dep && olen[r] <= (uint32_t)PNG_SHORT;
+                sidx[r] = (int)(S.op_r + off[r]) - (int)dist[r]; // > -RING
+                if (sidx[r] < 0)
+                    sidx[r] += PNG_RING;
+                else if (sidx[r] >= PNG_RING)
+                    sidx[r] -= PNG_RING;
+                ownm[r] = ballot(own[r]);
+            }
             wave_sync();
-            const uint64_t ownm = ballot(own);
-            if (ownm) {
-                if (nowrap && !ballot(own && sidx + PNG_SHORT > PNG_RING)) {
+            if (ownm[0] | ownm[1]) {
+                const uint64_t edge = ballot(own[0] && sidx[0] + PNG_SHORT > PNG_RING) | ballot(own[1] && sidx[1] + PNG_SHORT > PNG_RING);
+                if (nowrap && !edge) {
                     // the common case: no byte of these copies wraps.  All reads first (bytes behind a match's end are read
-                    // and dropped), then the writes: one LDS round trip for the whole pass.
-                    const bool any4 = ballot(own && olen > 3), any6 = ballot(own && olen > 5);
-                    uint32_t b[PNG_SHORT];
-                    if (own) {
+                    // and dropped; lanes without a copy read byte 0 and store into the sink), then the stores: one LDS round
+                    // trip for the whole pass, no exec masks.
+                    const bool any4 = ballot(own[0] && olen[0] > 3) | ballot(own[1] && olen[1] > 3);
+                    const bool any6 = ballot(own[0] && olen[0] > 5) | ballot(own[1] && olen[1] > 5);
+                    uint32_t b[2][PNG_SHORT];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const uint32_t sa = own[r] ? (uint32_t)sidx[r] : 0u;
 #pragma unroll
                         for (int k = 0; k < 3; ++k)
-                            b[k] = L.win[sidx + k];
-                        if (any4) {
-                            b[3] = L.win[sidx + 3];
-                            b[4] = L.win[sidx + 4];
+                            b[r][k] = win[sa + k];
+                    }
+                    if (any4) {
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            const uint32_t sa = own[r] ? (uint32_t)sidx[r] : 0u;
+                            b[r][3] = win[sa + 3];
+                            b[r][4] = win[sa + 4];
                         }
-                        if (any6) {
-                            b[5] = L.win[sidx + 5];
-                            b[6] = L.win[sidx + 6];
-                            b[7] = L.win[sidx + 7];
+                    }
+                    if (any6) {
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            const uint32_t sa = own[r] ? (uint32_t)sidx[r] : 0u;
+                            b[r][5] = win[sa + 5];
+                            b[r][6] = win[sa + 6];
+                            b[r][7] = win[sa + 7];
                         }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const uint32_t da = own[r] ? dst[r] : SINK;
 #pragma unroll
                         for (int k = 0; k < 3; ++k)
-                            L.win[dst + k] = (uint8_t)b[k];
-                        if (any4) {
-                            if (olen > 3)
-                                L.win[dst + 3] = (uint8_t)b[3];
-                            if (olen > 4)
-                                L.win[dst + 4] = (uint8_t)b[4];
+                            win[da + k] = (uint8_t)b[r][k];
+                    }
+                    if (any4) {
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            win[(own[r] && olen[r] > 3) ? dst[r] + 3 : SINK] = (uint8_t)b[r][3];
+                            win[(own[r] && olen[r] > 4) ? dst[r] + 4 : SINK] = (uint8_t)b[r][4];
                         }
-                        if (any6) {
-                            if (olen > 5)
-                                L.win[dst + 5] = (uint8_t)b[5];
-                            if (olen > 6)
-                                L.win[dst + 6] = (uint8_t)b[6];
-                            if (olen > 7)
-                                L.win[dst + 7] = (uint8_t)b[7];
+                    }
+                    if (any6) {
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            win[(own[r] && olen[r] > 5) ? dst[r] + 5 : SINK] = (uint8_t)b[r][5];
+                            win[(own[r] && olen[r] > 6) ? dst[r] + 6 : SINK] = (uint8_t)b[r][6];
+                            win[(own[r] && olen[r] > 7) ? dst[r] + 7 : SINK] = (uint8_t)b[r][7];
                         }
                     }
                 } else {
-                    uint32_t b[PNG_SHORT];
 #pragma unroll
-                    for (int k = 0; k < PNG_SHORT; ++k)
-                        b[k] = (own && (uint32_t)k < olen) ? (uint32_t)L.win[ring_wrap((uint32_t)sidx + k)] : 0u;
+                    for (int r = 0; r < 2; ++r) {
+                        uint32_t b[PNG_SHORT];
 #pragma unroll
-                    for (int k = 0; k < PNG_SHORT; ++k)
-                        if (own && (uint32_t)k < olen)
-                            L.win[ring_wrap(ring_wrap(S.op_r + off) + k)] = (uint8_t)b[k];
+                        for (int k = 0; k < PNG_SHORT; ++k)
+                            b[k] = (own[r] && (uint32_t)k < olen[r]) ? (uint32_t)win[ring_wrap((uint32_t)sidx[r] + k)] : 0u;
+#pragma unroll
+                        for (int k = 0; k < PNG_SHORT; ++k)
+                            if (own[r] && (uint32_t)k < olen[r])
+                                win[ring_wrap(ring_wrap(S.op_r + off[r]) + k)] = (uint8_t)b[k];
+                    }
                 }
             }
-            uint64_t rest = mm & ~ownm;
-            while (rest) {
-                const uint32_t j = (uint32_t)__builtin_ctzll(rest);
-                rest &= rest - 1;
-                const uint32_t o = rdl(off, j), len = rdl(olen, j), d = rdl(dist, j);
-                wave_sync();
-                const uint32_t dst0 = ring_wrap(S.op_r + o);
-                const uint32_t src0 = rdl((uint32_t)sidx, j);
-                const float rcp = 1.0f / (float)d;
-                for (uint32_t k0 = 0; k0 < len; k0 += 64) {
-                    const uint32_t k = k0 + lane;
-                    uint32_t r = k;
-                    if (d < len) { // overlapping: byte k repeats the pattern of d bytes
-                        const uint32_t q = (uint32_t)((float)k * rcp);
-                        int rr = (int)k - (int)(q * d);
-                        if (rr < 0)
-                            rr += (int)d;
-                        if (rr >= (int)d)
-                            rr -= (int)d;
-                        r = (uint32_t)rr;
-                    }
-                    if (k < len) {
-                        const uint8_t byte = L.win[ring_wrap(src0 + r)];
-                        L.win[ring_wrap(dst0 + k)] = byte;
+            // dependent, overlapping and long matches: one after the other in stream order, by the whole wave
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                uint64_t rest = mm[r] & ~ownm[r];
+                while (rest) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(rest);
+                    rest &= rest - 1;
+                    const uint32_t o = rdl(off[r], j), len = rdl(olen[r], j), d = rdl(dist[r], j);
+                    wave_sync();
+                    const uint32_t dst0 = ring_wrap(S.op_r + o);
+                    const uint32_t src0 = rdl((uint32_t)sidx[r], j);
+                    const float rcp = 1.0f / (float)d;
+                    for (uint32_t k0 = 0; k0 < len; k0 += 64) {
+                        const uint32_t k = k0 + lane;
+                        uint32_t q = k;
+                        if (d < len) { // overlapping: byte k repeats the pattern of d bytes
+                            const uint32_t quo = (uint32_t)((float)k * rcp);
+                            int rr = (int)k - (int)(quo * d);
+                            if (rr < 0)
+                                rr += (int)d;
+                            if (rr >= (int)d)
+                                rr -= (int)d;
+                            q = (uint32_t)rr;
+                        }
+                        if (k < len) {
+                            const uint8_t byte = win[ring_wrap(src0 + q)];
+                            win[ring_wrap(dst0 + k)] = byte;
+                        }
                     }
                 }
             }
         }
         png_advance(S, L, total, lane);
-        todo &= ~selm;
+        todo[0] &= ~selm[0];
+        todo[1] &= ~selm[1];
         consumed += total;
-    } while (todo);
+    } while (todo[0] | todo[1]);
     return 0;
 }
 // a stored block's bytes, straight from the stream
@@ -568,7 +633,7 @@ struct Sink {
     int lane;
     int dbg;        // measurement only: 1 = the records are dropped (what the parsing alone costs)
     // returns a status for !TWO; for TWO: 0, or -1 when the writing wave has gone (the parser then just stops)
-    __device__ __forceinline__ int put(uint32_t kind, uint32_t aux, uint64_t valid, uint32_t tok)
+    __device__ __forceinline__ int put(uint32_t kind, uint32_t aux, const uint64_t (&valid)[2], const uint32_t (&tok)[2])
     {
         if (!TWO) {
             const uint32_t k = kind & 3;
@@ -589,10 +654,13 @@ struct Sink {
             __builtin_amdgcn_s_sleep(1);
         }
         TokSlot &sl = L.q[head % PNG_NSLOT];
-        sl.tok[lane] = tok;
+        sl.tok[0][lane] = tok[0];
+        sl.tok[1][lane] = tok[1];
         if (lane == 0) {
-            sl.vlo = (uint32_t)valid;
-            sl.vhi = (uint32_t)(valid >> 32);
+            sl.v[0] = (uint32_t)valid[0];
+            sl.v[1] = (uint32_t)(valid[0] >> 32);
+            sl.v[2] = (uint32_t)valid[1];
+            sl.v[3] = (uint32_t)(valid[1] >> 32);
             sl.kind = kind;
             sl.aux = aux;
         }
@@ -601,6 +669,12 @@ struct Sink {
         if (lane == 0)
             q_st(&L.q_head, head);
         return 0;
+    }
+    __device__ __forceinline__ int put(uint32_t kind, uint32_t aux)
+    {
+        const uint64_t v[2] = {0, 0};
+        const uint32_t t[2] = {0, 0};
+        return put(kind, aux, v, t);
     }
 };
 
@@ -755,7 +829,7 @@ __device__ __forceinline__ int png_parse(Parser &P, InflateLds &L, Sink<TWO> &si
             if ((uint64_t)bp + len > P.zlen)
                 return ABUB_PNG_E_TRUNCATED;
             if (len) {
-                const int rc = sink.put(REC_STORED | (len << 2), bp, 0, 0);
+                const int rc = sink.put(REC_STORED | (len << 2), bp);
                 if (rc)
                     return rc;
             }
@@ -769,71 +843,109 @@ __device__ __forceinline__ int png_parse(Parser &P, InflateLds &L, Sink<TWO> &si
                 return rc;
         }
         // ---- tokens ----
-        uint32_t s = 0; // first real token start inside the window
+        uint32_t s = 0; // first real token start inside the two windows
         for (;;) {
             png_ensure(P, L, ip, lane);
             if (ip > P.nbits)
                 return ABUB_PNG_E_TRUNCATED;
-            // every lane: one token at bit offset ip + lane
+            // every lane: one token at bit offset ip + lane (window 0) and one at ip + 64 + lane (window 1; it only counts
+            // when window 0 does not end the block).  The two go through the look-ups side by side.
             const uint32_t pos = ip + lane, w = pos >> 5, sh = pos & 31;
-            const uint32_t d0 = L.in[w & (PNG_INDW - 1)], d1 = L.in[(w + 1) & (PNG_INDW - 1)], d2 = L.in[(w + 2) & (PNG_INDW - 1)];
-            const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
-            uint32_t e = L.lit[lo & ((1u << LIT_ROOT) - 1)];
-            if (ballot(e >> 31)) {
-                if (e >> 31)
-                    e = canon_slow<LIT_ROOT, false>(lo, L.cl, L.slit);
+            uint32_t d[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                d[k] = L.in[(w + k) & (PNG_INDW - 1)];
+            uint32_t lo[2], hi[2], e[2], nb[2], kind[2], tok[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                lo[r] = __builtin_amdgcn_alignbit(d[2 * r + 1], d[2 * r], sh);
+                hi[r] = __builtin_amdgcn_alignbit(d[2 * r + 2], d[2 * r + 1], sh);
+                e[r] = L.lit[lo[r] & ((1u << LIT_ROOT) - 1)];
             }
-            uint32_t nb = e & 15, kind = (e >> 4) & 3;
-            uint32_t tok = ((e >> 10) & 255u) << 1; // a literal's byte
-            if (ballot(kind == T_LEN)) {
-                const uint32_t eb = (e >> 6) & 15;
-                const uint32_t len = ((e >> 10) & 0x1fffffu) + __builtin_amdgcn_ubfe(lo, nb, eb);
-                const uint32_t nb2 = nb + eb;                              // <= 20
-                const uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, nb2); // the 32 bits behind the length code
-                uint32_t de = L.dist[w2 & ((1u << DIST_ROOT) - 1)];
-                if (ballot(kind == T_LEN && (de >> 31))) {
-                    if (kind == T_LEN && (de >> 31))
-                        de = canon_slow<DIST_ROOT, true>(w2, L.cd, L.sdist);
+            if (ballot(e[0] >> 31) | ballot(e[1] >> 31)) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    if (e[r] >> 31)
+                        e[r] = canon_slow<LIT_ROOT, false>(lo[r], L.cl, L.slit);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                nb[r] = e[r] & 15;
+                kind[r] = (e[r] >> 4) & 3;
+                tok[r] = ((e[r] >> 10) & 255u) << 1; // a literal's byte
+            }
+            if (ballot(kind[0] == T_LEN) | ballot(kind[1] == T_LEN)) {
+                uint32_t len[2], nb2[2], w2[2], de[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const uint32_t eb = (e[r] >> 6) & 15;
+                    len[r] = ((e[r] >> 10) & 0x1fffffu) + __builtin_amdgcn_ubfe(lo[r], nb[r], eb);
+                    nb2[r] = nb[r] + eb;                                       // <= 20
+                    w2[r] = __builtin_amdgcn_alignbit(hi[r], lo[r], nb2[r]);    // the 32 bits behind the length code
+                    de[r] = L.dist[w2[r] & ((1u << DIST_ROOT) - 1)];
                 }
-                const uint32_t dnb = de & 15, deb = (de >> 6) & 15; // dnb + deb <= 28
-                const uint32_t dd = ((de >> 10) & 0x1fffffu) + __builtin_amdgcn_ubfe(w2, dnb, deb);
-                if (kind == T_LEN) {
-                    tok = 1u | (len << 1) | (dd << 10);
-                    nb = nb2 + dnb + deb;
-                    if (((de >> 4) & 3) == T_BAD)
-                        kind = T_BAD;
+                if (ballot(kind[0] == T_LEN && (de[0] >> 31)) | ballot(kind[1] == T_LEN && (de[1] >> 31))) {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+                        if (kind[r] == T_LEN && (de[r] >> 31))
+                            de[r] = canon_slow<DIST_ROOT, true>(w2[r], L.cd, L.sdist);
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const uint32_t dnb = de[r] & 15, deb = (de[r] >> 6) & 15; // dnb + deb <= 28
+                    const uint32_t dd = ((de[r] >> 10) & 0x1fffffu) + __builtin_amdgcn_ubfe(w2[r], dnb, deb);
+                    if (kind[r] == T_LEN) {
+                        tok[r] = 1u | (len[r] << 1) | (dd << 10);
+                        nb[r] = nb2[r] + dnb + deb;
+                        if (((de[r] >> 4) & 3) == T_BAD)
+                            kind[r] = T_BAD;
+                    }
                 }
             }
             // ---- the chain of real tokens: s, s + n(s), ...  (an invalid code advances by one bit: looked at afterwards) ----
-            const uint32_t step = kind == T_BAD ? 1u : nb;
-            uint64_t valid = 0;
+            const uint32_t step0 = kind[0] == T_BAD ? 1u : nb[0], step1 = kind[1] == T_BAD ? 1u : nb[1];
+            uint64_t valid[2] = {0, 0};
             uint32_t p = s;
             do {
-                valid |= 1ull << p;
-                p += rdl(step, p);
+                valid[0] |= 1ull << p;
+                p += rdl(step0, p);
+            } while (p < 64);
+            p -= 64;
+            do {
+                valid[1] |= 1ull << p;
+                p += rdl(step1, p);
             } while (p < 64);
             bool eob = false;
             {
                 // end of block or an invalid code on the chain: what follows is not data
-                const uint64_t stop = ballot(((valid >> lane) & 1) && kind >= T_EOB);
-                if (stop) {
-                    const uint32_t j = (uint32_t)__builtin_ctzll(stop);
-                    if (rdl(kind, j) == T_BAD)
+                const uint64_t stop0 = ballot(((valid[0] >> lane) & 1) && kind[0] >= T_EOB);
+                const uint64_t stop1 = ballot(((valid[1] >> lane) & 1) && kind[1] >= T_EOB);
+                if (stop0) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(stop0);
+                    if (rdl(kind[0], j) == T_BAD)
                         return ABUB_PNG_E_CODE;
-                    valid &= (1ull << j) - 1; // (the end-of-block token itself carries no bytes)
-                    p = j + rdl(nb, j);
+                    valid[0] &= (1ull << j) - 1; // (the end-of-block token itself carries no bytes)
+                    valid[1] = 0;
+                    p = j + rdl(nb[0], j);
+                    eob = true;
+                } else if (stop1) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(stop1);
+                    if (rdl(kind[1], j) == T_BAD)
+                        return ABUB_PNG_E_CODE;
+                    valid[1] &= (1ull << j) - 1;
+                    p = 64 + j + rdl(nb[1], j);
                     eob = true;
                 }
             }
             if (eob)
                 ip += p;
             else {
-                ip += 64;
+                ip += 128;
                 s = p - 64;
             }
             if (ip > P.nbits)
                 return ABUB_PNG_E_TRUNCATED;
-            if (valid) {
+            if (valid[0] | valid[1]) {
                 const int rc = sink.put(REC_TOKENS, 0, valid, tok);
                 if (rc)
                     return rc;
@@ -848,7 +960,7 @@ __device__ __forceinline__ int png_parse(Parser &P, InflateLds &L, Sink<TWO> &si
         return ABUB_PNG_E_TRUNCATED;
     png_ensure(P, L, ip, lane);
     const uint32_t adler = __builtin_bswap32(rfl(png_bits32(L, ip)));
-    return sink.put(REC_END, adler, 0, 0);
+    return sink.put(REC_END, adler);
 }
 
 template <bool TWO>
@@ -889,7 +1001,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_png_inflate(const uint8_t *_
             if (lane == 0)
                 status[f] = rc;
         } else if (rc > 0)
-            (void)sink.put(REC_ERROR, (uint32_t)rc, 0, 0); // (rc == -1: the writing wave has set the status and gone)
+            (void)sink.put(REC_ERROR, (uint32_t)rc); // (rc == -1: the writing wave has set the status and gone)
         return;
     }
     // the writing wave
@@ -909,8 +1021,8 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_png_inflate(const uint8_t *_
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const TokSlot &sl = L.q[tail % PNG_NSLOT];
         const uint32_t kind = rfl(sl.kind), aux = rfl(sl.aux);
-        const uint64_t valid = ((uint64_t)rfl(sl.vhi) << 32) | rfl(sl.vlo);
-        const uint32_t tok = sl.tok[lane];
+        const uint64_t valid[2] = {((uint64_t)rfl(sl.v[1]) << 32) | rfl(sl.v[0]), ((uint64_t)rfl(sl.v[3]) << 32) | rfl(sl.v[2])};
+        const uint32_t tok[2] = {sl.tok[0][lane], sl.tok[1][lane]};
         // (the record is in registers: the slot may be refilled while its tokens are applied)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         ++tail;
