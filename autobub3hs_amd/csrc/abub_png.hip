@@ -238,7 +238,7 @@ struct TokSlot {
     uint32_t pad[2];
 };
 struct InflateLds {
-    alignas(16) uint8_t win[PNG_RING];
+    alignas(16) uint8_t win[PNG_RING + 16]; // the ring, then a copy of its first bytes (a short read never has to wrap)
     alignas(16) uint32_t in[PNG_INDW];
     uint32_t lit[1 << LIT_ROOT];   // while a block's header is read, its code lengths live here (hdr_lens() ...)
     uint32_t dist[1 << DIST_ROOT];
@@ -327,6 +327,7 @@ struct Writer {
     uint32_t op, op_r; // output position, and the same modulo the ring
     uint32_t fp;       // flushed up to here (multiple of 16)
     uint32_t a1, a2;   // Adler-32 of the flushed bytes
+    bool far;          // this lane saw a distance that reaches before the output's first byte (checked at every flush)
 };
 
 __device__ __forceinline__ uint32_t png_load4(const Parser &P, uint32_t off)
@@ -403,8 +404,14 @@ __device__ __forceinline__ void png_flush(Writer &S, InflateLds &L, uint32_t upt
 }
 __device__ __forceinline__ void png_advance(Writer &S, InflateLds &L, uint32_t total, int lane)
 {
+    const uint32_t o0 = S.op_r;
     S.op += total;
-    S.op_r = ring_wrap(S.op_r + total);
+    S.op_r = ring_wrap(o0 + total);
+    if (o0 < 16 || S.op_r < o0) { // the ring's first bytes were written: renew their copy behind its end
+        wave_sync();
+        if (lane < 16)
+            L.win[PNG_RING + lane] = L.win[lane];
+    }
     if (S.op - S.fp >= (uint32_t)PNG_FLUSH) {
         wave_sync();
         png_flush(S, L, S.op & ~15u, false, lane);
@@ -449,127 +456,117 @@ __device__ __forceinline__ int png_apply(Writer &S, InflateLds &L, const uint64_
         if (S.op + total > S.rawLen)
             return ABUB_PNG_E_TOOMUCH;
         const bool nowrap = S.op_r + (uint32_t)PNG_CAP + 264 <= (uint32_t)PNG_RING; // no destination of this pass wraps
-        uint32_t off[2], dst[2];
-        bool isMatch[2];
-        uint64_t mm[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            off[r] = incl[r] - olen[r] - consumed;
-            dst[r] = nowrap ? S.op_r + off[r] : ring_wrap(S.op_r + off[r]);
-            isMatch[r] = sel[r] && isM[r];
-            mm[r] = ballot(isMatch[r]);
-        }
-        if (dbg != 3) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-                win[(sel[r] && !isM[r]) ? dst[r] : SINK] = (uint8_t)lit[r];
-        }
-        if ((mm[0] | mm[1]) && dbg < 2) {
-            if (ballot(isMatch[0] && dist[0] > S.op + off[0]) | ballot(isMatch[1] && dist[1] > S.op + off[1]))
-                return ABUB_PNG_E_DISTANCE;
-            // output offset of the pass's first match: a match whose source ends behind it may read what an earlier match of
-            // this pass writes
-            const uint32_t m0 = mm[0] ? rdl(off[0], (uint32_t)__builtin_ctzll(mm[0])) : rdl(off[1], (uint32_t)__builtin_ctzll(mm[1]));
-            bool own[2];
-            int sidx[2];
-            uint64_t ownm[2];
+        if (nowrap) {
+            // ---- the common pass: straight-line, three branches ----
+            // A short match whose source lies wholly before this pass's first byte is copied by its own lane: 5 bytes read
+            // and stored at once (8 when some match is longer; bytes behind a match's end go to the sink), no wrap to think
+            // of (a source that runs over the ring's end reads the copy of the ring's first bytes kept there).  The others
+            // -- sources inside this pass, overlapping or long ones -- follow one by one in stream order.
+            uint32_t dst[2], sa[2];
+            bool own[2], slow[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const bool dep = isMatch[r] && (int)(off[r] + olen[r]) - (int)dist[r] > (int)m0;
-                own[r] = isMatch[r] && !dep && olen[r] <= (uint32_t)PNG_SHORT;
-                sidx[r] = (int)(S.op_r + off[r]) - (int)dist[r]; // > -RING
-                if (sidx[r] < 0)
-                    sidx[r] += PNG_RING;
-                else if (sidx[r] >= PNG_RING)
-                    sidx[r] -= PNG_RING;
-                ownm[r] = ballot(own[r]);
+                const uint32_t off = incl[r] - olen[r] - consumed;
+                dst[r] = S.op_r + off;
+                const bool isMatch = sel[r] && isM[r];
+                S.far |= isMatch && dist[r] > S.op + off; // (looked at when the ring is flushed: the bytes are not out before that)
+                own[r] = isMatch && dist[r] >= off + olen[r] && olen[r] <= (uint32_t)PNG_SHORT;
+                slow[r] = isMatch && !own[r];
+                int si = (int)dst[r] - (int)dist[r]; // > -RING
+                if (si < 0)
+                    si += PNG_RING;
+                sa[r] = own[r] ? (uint32_t)si : 0u;
+                if (dbg != 3)
+                    win[(sel[r] && !isM[r]) ? dst[r] : SINK] = (uint8_t)lit[r];
             }
-            wave_sync();
-            if (ownm[0] | ownm[1]) {
-                const uint64_t edge = ballot(own[0] && sidx[0] + PNG_SHORT > PNG_RING) | ballot(own[1] && sidx[1] + PNG_SHORT > PNG_RING);
-                if (nowrap && !edge) {
-                    // the common case: no byte of these copies wraps.  All reads first (bytes behind a match's end are read
-                    // and dropped; lanes without a copy read byte 0 and store into the sink), then the stores: one LDS round
-                    // trip for the whole pass, no exec masks.
-                    const bool any4 = ballot(own[0] && olen[0] > 3) | ballot(own[1] && olen[1] > 3);
-                    const bool any6 = ballot(own[0] && olen[0] > 5) | ballot(own[1] && olen[1] > 5);
-                    uint32_t b[2][PNG_SHORT];
+            if (dbg < 2) {
+                const bool any6 = ballot(own[0] && olen[0] > 5) | ballot(own[1] && olen[1] > 5);
+                uint32_t b[2][PNG_SHORT];
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int k = 0; k < 5; ++k)
+                        b[r][k] = win[sa[r] + k];
+                if (any6) {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int k = 5; k < PNG_SHORT; ++k)
+                            b[r][k] = win[sa[r] + k];
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const uint32_t da = own[r] ? dst[r] : SINK;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        win[da + k] = (uint8_t)b[r][k];
+                    win[(own[r] && olen[r] > 3) ? dst[r] + 3 : SINK] = (uint8_t)b[r][3];
+                    win[(own[r] && olen[r] > 4) ? dst[r] + 4 : SINK] = (uint8_t)b[r][4];
+                }
+                if (any6) {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int k = 5; k < PNG_SHORT; ++k)
+                            win[(own[r] && olen[r] > (uint32_t)k) ? dst[r] + k : SINK] = (uint8_t)b[r][k];
+                }
+                const uint64_t rest0 = ballot(slow[0]), rest1 = ballot(slow[1]);
+                if (rest0 | rest1) {
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
-                        const uint32_t sa = own[r] ? (uint32_t)sidx[r] : 0u;
-#pragma unroll
-                        for (int k = 0; k < 3; ++k)
-                            b[r][k] = win[sa + k];
-                    }
-                    if (any4) {
-#pragma unroll
-                        for (int r = 0; r < 2; ++r) {
-                            const uint32_t sa = own[r] ? (uint32_t)sidx[r] : 0u;
-                            b[r][3] = win[sa + 3];
-                            b[r][4] = win[sa + 4];
+                        uint64_t rest = r ? rest1 : rest0;
+                        while (rest) {
+                            const uint32_t j = (uint32_t)__builtin_ctzll(rest);
+                            rest &= rest - 1;
+                            const uint32_t len = rdl(olen[r], j), d = rdl(dist[r], j), dst0 = rdl(dst[r], j);
+                            wave_sync();
+                            int s0 = (int)dst0 - (int)d;
+                            if (s0 < 0)
+                                s0 += PNG_RING;
+                            const float rcp = 1.0f / (float)d;
+                            for (uint32_t k0 = 0; k0 < len; k0 += 64) {
+                                const uint32_t k = k0 + lane;
+                                uint32_t q = k;
+                                if (d < len) { // overlapping: byte k repeats the pattern of d bytes
+                                    const uint32_t quo = (uint32_t)((float)k * rcp);
+                                    int rr = (int)k - (int)(quo * d);
+                                    if (rr < 0)
+                                        rr += (int)d;
+                                    if (rr >= (int)d)
+                                        rr -= (int)d;
+                                    q = (uint32_t)rr;
+                                }
+                                if (k < len) {
+                                    const uint8_t byte = win[ring_wrap((uint32_t)s0 + q)];
+                                    win[dst0 + k] = byte;
+                                }
+                            }
                         }
-                    }
-                    if (any6) {
-#pragma unroll
-                        for (int r = 0; r < 2; ++r) {
-                            const uint32_t sa = own[r] ? (uint32_t)sidx[r] : 0u;
-                            b[r][5] = win[sa + 5];
-                            b[r][6] = win[sa + 6];
-                            b[r][7] = win[sa + 7];
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        const uint32_t da = own[r] ? dst[r] : SINK;
-#pragma unroll
-                        for (int k = 0; k < 3; ++k)
-                            win[da + k] = (uint8_t)b[r][k];
-                    }
-                    if (any4) {
-#pragma unroll
-                        for (int r = 0; r < 2; ++r) {
-                            win[(own[r] && olen[r] > 3) ? dst[r] + 3 : SINK] = (uint8_t)b[r][3];
-                            win[(own[r] && olen[r] > 4) ? dst[r] + 4 : SINK] = (uint8_t)b[r][4];
-                        }
-                    }
-                    if (any6) {
-#pragma unroll
-                        for (int r = 0; r < 2; ++r) {
-                            win[(own[r] && olen[r] > 5) ? dst[r] + 5 : SINK] = (uint8_t)b[r][5];
-                            win[(own[r] && olen[r] > 6) ? dst[r] + 6 : SINK] = (uint8_t)b[r][6];
-                            win[(own[r] && olen[r] > 7) ? dst[r] + 7 : SINK] = (uint8_t)b[r][7];
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        uint32_t b[PNG_SHORT];
-#pragma unroll
-                        for (int k = 0; k < PNG_SHORT; ++k)
-                            b[k] = (own[r] && (uint32_t)k < olen[r]) ? (uint32_t)win[ring_wrap((uint32_t)sidx[r] + k)] : 0u;
-#pragma unroll
-                        for (int k = 0; k < PNG_SHORT; ++k)
-                            if (own[r] && (uint32_t)k < olen[r])
-                                win[ring_wrap(ring_wrap(S.op_r + off[r]) + k)] = (uint8_t)b[k];
                     }
                 }
             }
-            // dependent, overlapping and long matches: one after the other in stream order, by the whole wave
+        } else {
+            // ---- a pass near the ring's end (one in ~60): every index wrapped, every match in stream order ----
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                uint64_t rest = mm[r] & ~ownm[r];
+                const uint32_t off = incl[r] - olen[r] - consumed;
+                const bool isMatch = sel[r] && isM[r];
+                S.far |= isMatch && dist[r] > S.op + off;
+                if (sel[r] && !isM[r] && dbg != 3)
+                    win[ring_wrap(S.op_r + off)] = (uint8_t)lit[r];
+                uint64_t rest = dbg < 2 ? ballot(isMatch) : 0;
                 while (rest) {
                     const uint32_t j = (uint32_t)__builtin_ctzll(rest);
                     rest &= rest - 1;
-                    const uint32_t o = rdl(off[r], j), len = rdl(olen[r], j), d = rdl(dist[r], j);
+                    const uint32_t o = rdl(off, j), len = rdl(olen[r], j), d = rdl(dist[r], j);
                     wave_sync();
                     const uint32_t dst0 = ring_wrap(S.op_r + o);
-                    const uint32_t src0 = rdl((uint32_t)sidx[r], j);
+                    const uint32_t src0 = ring_wrap(ring_wrap(S.op_r + o + PNG_RING - min(d, (uint32_t)PNG_RING)));
                     const float rcp = 1.0f / (float)d;
                     for (uint32_t k0 = 0; k0 < len; k0 += 64) {
                         const uint32_t k = k0 + lane;
                         uint32_t q = k;
-                        if (d < len) { // overlapping: byte k repeats the pattern of d bytes
+                        if (d < len) {
                             const uint32_t quo = (uint32_t)((float)k * rcp);
                             int rr = (int)k - (int)(quo * d);
                             if (rr < 0)
@@ -613,6 +610,8 @@ __device__ __forceinline__ int png_apply_end(Writer &S, InflateLds &L, uint32_t 
 {
     wave_sync();
     png_flush(S, L, S.op, true, lane);
+    if (ballot(S.far))
+        return ABUB_PNG_E_DISTANCE;
     if (S.op != S.rawLen)
         return ABUB_PNG_E_TOOLITTLE;
     return adler == ((S.a2 << 16) | S.a1) ? 0 : ABUB_PNG_E_ADLER;
@@ -630,6 +629,7 @@ struct Sink {
     InflateLds &L;
     Writer *W;      // !TWO
     uint32_t head;  // TWO
+    uint32_t tail_pf; // TWO: the consumer's counter as last seen
     int lane;
     int dbg;        // measurement only: 1 = the records are dropped (what the parsing alone costs)
     // returns a status for !TWO; for TWO: 0, or -1 when the writing wave has gone (the parser then just stops)
@@ -637,7 +637,7 @@ struct Sink {
     {
         if (!TWO) {
             const uint32_t k = kind & 3;
-            if (dbg == 1)
+            if (dbg == 1 || dbg == 4)
                 return 0;
             if (k == REC_TOKENS)
                 return png_apply(*W, L, valid, tok, lane, dbg);
@@ -647,8 +647,12 @@ struct Sink {
                 return dbg ? 0 : png_apply_end(*W, L, aux, lane);
             return (int)aux;
         }
+        // (tail_pf was requested when the last record went out: it is here by now, and usually says "room")
         uint32_t spins = 0;
-        while (head - q_ld(&L.q_tail) >= (uint32_t)PNG_NSLOT) {
+        while (head - tail_pf >= (uint32_t)PNG_NSLOT) {
+            tail_pf = q_ld(&L.q_tail);
+            if (head - tail_pf < (uint32_t)PNG_NSLOT)
+                break;
             if (q_ld(&L.q_abort) || ++spins > PNG_SPINS)
                 return -1;
             __builtin_amdgcn_s_sleep(1);
@@ -664,10 +668,12 @@ struct Sink {
             sl.kind = kind;
             sl.aux = aux;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // (a wave's LDS operations execute in order: the counter's store follows the record's without waiting for them)
+        wave_sync();
         ++head;
         if (lane == 0)
             q_st(&L.q_head, head);
+        tail_pf = q_ld(&L.q_tail);
         return 0;
     }
     __device__ __forceinline__ int put(uint32_t kind, uint32_t aux)
@@ -855,85 +861,98 @@ __device__ __forceinline__ int png_parse(Parser &P, InflateLds &L, Sink<TWO> &si
 #pragma unroll
             for (int k = 0; k < 5; ++k)
                 d[k] = L.in[(w + k) & (PNG_INDW - 1)];
-            uint32_t lo[2], hi[2], e[2], nb[2], kind[2], tok[2];
+            uint32_t lo[2], hi[2], e[2], de[2], w2[2], nb[2], kind[2], tok[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 lo[r] = __builtin_amdgcn_alignbit(d[2 * r + 1], d[2 * r], sh);
                 hi[r] = __builtin_amdgcn_alignbit(d[2 * r + 2], d[2 * r + 1], sh);
                 e[r] = L.lit[lo[r] & ((1u << LIT_ROOT) - 1)];
             }
-            if (ballot(e[0] >> 31) | ballot(e[1] >> 31)) {
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-                    if (e[r] >> 31)
-                        e[r] = canon_slow<LIT_ROOT, false>(lo[r], L.cl, L.slit);
-            }
+            // the distance code behind a length code (looked up for every lane: the ones without a length code drop it)
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                nb[r] = e[r] & 15;
+                const uint32_t nb2 = (e[r] & 15) + ((e[r] >> 6) & 15);   // <= 20
+                w2[r] = __builtin_amdgcn_alignbit(hi[r], lo[r], nb2);     // the 32 bits behind the length code
+                de[r] = L.dist[w2[r] & ((1u << DIST_ROOT) - 1)];
+            }
+            // A lane whose bits start a code longer than the tables' index is left for later (it advances by one bit like an
+            // invalid code): nearly all of them are lanes the chain never visits -- half of the records have such a lane
+            // somewhere among their 128, a few per cent have one ON the chain.
+            bool lng[2];
+            auto finish = [&](int r) {
+                const uint32_t lnb = e[r] & 15, eb = (e[r] >> 6) & 15, base = (e[r] >> 10) & 0x1fffffu;
                 kind[r] = (e[r] >> 4) & 3;
-                tok[r] = ((e[r] >> 10) & 255u) << 1; // a literal's byte
-            }
-            if (ballot(kind[0] == T_LEN) | ballot(kind[1] == T_LEN)) {
-                uint32_t len[2], nb2[2], w2[2], de[2];
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const uint32_t eb = (e[r] >> 6) & 15;
-                    len[r] = ((e[r] >> 10) & 0x1fffffu) + __builtin_amdgcn_ubfe(lo[r], nb[r], eb);
-                    nb2[r] = nb[r] + eb;                                       // <= 20
-                    w2[r] = __builtin_amdgcn_alignbit(hi[r], lo[r], nb2[r]);    // the 32 bits behind the length code
-                    de[r] = L.dist[w2[r] & ((1u << DIST_ROOT) - 1)];
-                }
-                if (ballot(kind[0] == T_LEN && (de[0] >> 31)) | ballot(kind[1] == T_LEN && (de[1] >> 31))) {
-#pragma unroll
-                    for (int r = 0; r < 2; ++r)
-                        if (kind[r] == T_LEN && (de[r] >> 31))
-                            de[r] = canon_slow<DIST_ROOT, true>(w2[r], L.cd, L.sdist);
-                }
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const uint32_t dnb = de[r] & 15, deb = (de[r] >> 6) & 15; // dnb + deb <= 28
-                    const uint32_t dd = ((de[r] >> 10) & 0x1fffffu) + __builtin_amdgcn_ubfe(w2[r], dnb, deb);
-                    if (kind[r] == T_LEN) {
-                        tok[r] = 1u | (len[r] << 1) | (dd << 10);
-                        nb[r] = nb2[r] + dnb + deb;
-                        if (((de[r] >> 4) & 3) == T_BAD)
-                            kind[r] = T_BAD;
-                    }
-                }
-            }
+                const uint32_t len = base + __builtin_amdgcn_ubfe(lo[r], lnb, eb);
+                const uint32_t dnb = de[r] & 15, deb = (de[r] >> 6) & 15; // dnb + deb <= 28
+                const uint32_t dd = ((de[r] >> 10) & 0x1fffffu) + __builtin_amdgcn_ubfe(w2[r], dnb, deb);
+                const bool isLen = kind[r] == T_LEN;
+                lng[r] = (e[r] >> 31) || (isLen && (de[r] >> 31));
+                tok[r] = isLen ? (1u | (len << 1) | (dd << 10)) : ((base & 255u) << 1);
+                nb[r] = isLen ? lnb + eb + dnb + deb : lnb;
+                if (isLen && ((de[r] >> 4) & 3) == T_BAD)
+                    kind[r] = T_BAD;
+            };
+            finish(0);
+            finish(1);
             // ---- the chain of real tokens: s, s + n(s), ...  (an invalid code advances by one bit: looked at afterwards) ----
-            const uint32_t step0 = kind[0] == T_BAD ? 1u : nb[0], step1 = kind[1] == T_BAD ? 1u : nb[1];
-            uint64_t valid[2] = {0, 0};
-            uint32_t p = s;
-            do {
-                valid[0] |= 1ull << p;
-                p += rdl(step0, p);
-            } while (p < 64);
-            p -= 64;
-            do {
-                valid[1] |= 1ull << p;
-                p += rdl(step1, p);
-            } while (p < 64);
+            uint64_t valid[2];
+            uint32_t p;
+            auto walk = [&]() {
+                const uint32_t step0 = (kind[0] == T_BAD) ? 1u : nb[0], step1 = (kind[1] == T_BAD) ? 1u : nb[1];
+                valid[0] = valid[1] = 0;
+                p = s;
+                do {
+                    valid[0] |= 1ull << p;
+                    p += rdl(step0, p);
+                } while (p < 64);
+                p -= 64;
+                do {
+                    valid[1] |= 1ull << p;
+                    p += rdl(step1, p);
+                } while (p < 64);
+            };
+            if (sink.dbg == 4) { // (measurement only: what everything but the walk costs)
+                valid[0] = valid[1] = 0x0101010101010101ull;
+                p = 64 + (rdl(nb[0], 0) & 1) + (rdl(nb[1], 0) & 1);
+            } else {
+                walk();
+                if (ballot(((valid[0] >> lane) & 1) && lng[0]) | ballot(((valid[1] >> lane) & 1) && lng[1])) {
+                    // a long code on the chain: the canonical compare for every lane that has one, then the walk again
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        if (e[r] >> 31) {
+                            e[r] = canon_slow<LIT_ROOT, false>(lo[r], L.cl, L.slit);
+                            const uint32_t nb2 = (e[r] & 15) + ((e[r] >> 6) & 15);
+                            w2[r] = __builtin_amdgcn_alignbit(hi[r], lo[r], nb2);
+                            de[r] = L.dist[w2[r] & ((1u << DIST_ROOT) - 1)];
+                        }
+                        if (((e[r] >> 4) & 3) == T_LEN && (de[r] >> 31))
+                            de[r] = canon_slow<DIST_ROOT, true>(w2[r], L.cd, L.sdist);
+                        finish(r);
+                    }
+                    walk();
+                }
+            }
             bool eob = false;
             {
                 // end of block or an invalid code on the chain: what follows is not data
                 const uint64_t stop0 = ballot(((valid[0] >> lane) & 1) && kind[0] >= T_EOB);
                 const uint64_t stop1 = ballot(((valid[1] >> lane) & 1) && kind[1] >= T_EOB);
-                if (stop0) {
-                    const uint32_t j = (uint32_t)__builtin_ctzll(stop0);
-                    if (rdl(kind[0], j) == T_BAD)
-                        return ABUB_PNG_E_CODE;
-                    valid[0] &= (1ull << j) - 1; // (the end-of-block token itself carries no bytes)
-                    valid[1] = 0;
-                    p = j + rdl(nb[0], j);
-                    eob = true;
-                } else if (stop1) {
-                    const uint32_t j = (uint32_t)__builtin_ctzll(stop1);
-                    if (rdl(kind[1], j) == T_BAD)
-                        return ABUB_PNG_E_CODE;
-                    valid[1] &= (1ull << j) - 1;
-                    p = 64 + j + rdl(nb[1], j);
+                if ((stop0 | stop1) && sink.dbg != 4) {
+                    if (stop0) {
+                        const uint32_t j = (uint32_t)__builtin_ctzll(stop0);
+                        if (rdl(kind[0], j) == T_BAD)
+                            return ABUB_PNG_E_CODE;
+                        valid[0] &= (1ull << j) - 1; // (the end-of-block token itself carries no bytes)
+                        valid[1] = 0;
+                        p = j + rdl(nb[0], j);
+                    } else {
+                        const uint32_t j = (uint32_t)__builtin_ctzll(stop1);
+                        if (rdl(kind[1], j) == T_BAD)
+                            return ABUB_PNG_E_CODE;
+                        valid[1] &= (1ull << j) - 1;
+                        p = 64 + j + rdl(nb[1], j);
+                    }
                     eob = true;
                 }
             }
@@ -989,13 +1008,14 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_png_inflate(const uint8_t *_
     W.op = W.op_r = W.fp = 0;
     W.a1 = 1;
     W.a2 = 0;
+    W.far = false;
     if (!TWO || wave == 0) {
         Parser P;
         P.z = zbuf + fr.zoff;
         P.zlen = fr.zlen;
         P.zpad = (fr.zlen + 15) & ~15u;
         P.nbits = fr.zlen * 8;
-        Sink<TWO> sink = {L, &W, 0, lane, dbg};
+        Sink<TWO> sink = {L, &W, 0, 0, lane, dbg};
         int rc = png_parse<TWO>(P, L, sink, lane);
         if (!TWO) {
             if (lane == 0)
@@ -1018,13 +1038,13 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_png_inflate(const uint8_t *_
         }
         if (rc)
             break;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        wave_sync();
         const TokSlot &sl = L.q[tail % PNG_NSLOT];
         const uint32_t kind = rfl(sl.kind), aux = rfl(sl.aux);
         const uint64_t valid[2] = {((uint64_t)rfl(sl.v[1]) << 32) | rfl(sl.v[0]), ((uint64_t)rfl(sl.v[3]) << 32) | rfl(sl.v[2])};
         const uint32_t tok[2] = {sl.tok[0][lane], sl.tok[1][lane]};
         // (the record is in registers: the slot may be refilled while its tokens are applied)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        wave_sync(); // (in-order LDS: the slot's loads execute before the counter's store)
         ++tail;
         if (lane == 0)
             q_st(&L.q_tail, tail);
