@@ -26,10 +26,10 @@
 namespace {
 
 constexpr int PNG_WIN = 32768;   // deflate history
-constexpr int PNG_CAP = 288;     // output bytes one pass over a record's tokens may produce (ring = history + this; >= 258)
+constexpr int PNG_CAP = 512;     // output bytes one pass over a record's tokens may produce (ring = history + this)
 constexpr int PNG_RING = PNG_WIN + PNG_CAP;
-constexpr int PNG_INDW = 64;     // input ring in dwords (256 B, refilled 128 B at a time, one refill prefetched in registers)
-constexpr int PNG_NSLOT = 3;     // token records in flight between the waves of a stream
+constexpr int PNG_INDW = 128;    // input ring in dwords (512 B, refilled 256 B at a time, one refill prefetched in registers)
+constexpr int PNG_NSLOT = 2;     // token records in flight between the parsing and the writing wave
 constexpr int PNG_FLUSH = 2048;  // unflushed output that triggers a flush
 constexpr int LIT_ROOT = 10, DIST_ROOT = 8;
 constexpr int PNG_SHORT = 8;     // matches up to this length are copied by their own lane
@@ -246,9 +246,7 @@ struct InflateLds {
     uint16_t sdist[32];
     CanonLds cl, cd;
     TokSlot q[PNG_NSLOT];
-    uint32_t q_head, q_tail, q_abort; // records produced / consumed (two waves: parser -> writer; three: lexer -> ... -> writer)
-    uint32_t q_mid;                   // three waves: records the walker has passed on to the writer
-    uint32_t c_cmd, c_state, c_ip;    // three waves: the walker's orders to the lexer, the lexer's answer, where to start
+    uint32_t q_head, q_tail, q_abort, q_pad;
     uint8_t sink[16]; // where the byte stores of lanes that have nothing to store go (straight-line code, no exec masks)
 };
 // scratch of the header parse inside the (then dead) literal table: lens[320] | cl[32] | scl[32] (u16)
@@ -319,7 +317,7 @@ struct Parser {
     uint32_t zlen;
     uint32_t zpad;     // its length rounded up to 16 (readable, zero-filled behind the stream)
     uint32_t nbits;    // its length in bits
-    uint32_t in_hi;    // the input ring holds the stream's bytes [in_hi - 256, in_hi)
+    uint32_t in_hi;    // the input ring holds the stream's bytes [in_hi - 512, in_hi)
     uint32_t pf;       // bytes [in_hi + 4 * lane, + 4), requested ahead
 };
 struct Writer {
@@ -341,17 +339,16 @@ __device__ __forceinline__ uint32_t png_load4(const Parser &P, uint32_t off)
 }
 __device__ __forceinline__ void png_refill(Parser &P, InflateLds &L, int lane)
 {
-    if (lane < 32)
-        L.in[((P.in_hi & (PNG_INDW * 4 - 1)) >> 2) + lane] = P.pf;
-    P.in_hi += 128;
-    P.pf = lane < 32 ? png_load4(P, P.in_hi + 4 * lane) : 0u;
+    L.in[((P.in_hi & (PNG_INDW * 4 - 1)) >> 2) + lane] = P.pf;
+    P.in_hi += 256;
+    P.pf = png_load4(P, P.in_hi + 4 * lane);
     wave_sync();
 }
 // (re)start the input ring at bit position ip
 __device__ __forceinline__ void png_in_start(Parser &P, InflateLds &L, uint32_t ip, int lane)
 {
-    P.in_hi = (ip >> 3) & ~127u;
-    P.pf = lane < 32 ? png_load4(P, P.in_hi + 4 * lane) : 0u;
+    P.in_hi = (ip >> 3) & ~255u;
+    P.pf = png_load4(P, P.in_hi + 4 * lane);
     png_refill(P, L, lane);
 }
 // the ring covers every dword the window reads at bit positions ip .. ip + 127 touch (and 32-bit peeks at ip)
@@ -688,48 +685,8 @@ struct Sink {
 };
 
 // ---- the parsing side ----
-// Where a block's header bits come from: the LDS input ring (one- and two-wave kernels: the parsing wave owns it) ...
-struct RingBits {
-    Parser &P;
-    InflateLds &L;
-    uint32_t nbits;
-    __device__ __forceinline__ void ensure(uint32_t ip, int lane) { png_ensure(P, L, ip, lane); }
-    __device__ __forceinline__ uint32_t u32(uint32_t pos) { return rfl(png_bits32(L, pos)); } // (pos uniform, inside the ensured range)
-};
-// ... or 512 bytes of the stream held in two registers per lane and read with v_readlane (three-wave kernel: the input ring
-// belongs to the lexer, the walker reads headers on its own)
-struct RegBits {
-    const uint8_t *z;
-    uint32_t zpad, nbits;
-    uint32_t base; // byte offset (a multiple of 4) of lane 0's dword of hw[0]
-    uint32_t hw[2];
-    __device__ __forceinline__ void load(uint32_t ip, int lane)
-    {
-        base = (ip >> 3) & ~3u;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const uint32_t off = base + 4 * (lane + 64 * q);
-            hw[q] = off + 4 <= zpad ? *(const uint32_t *)(z + off) : 0u;
-        }
-    }
-    __device__ __forceinline__ void ensure(uint32_t ip, int lane)
-    {
-        const uint32_t by = ip >> 3;
-        if (by < base || by + 24 > base + 512)
-            load(ip, lane);
-    }
-    __device__ __forceinline__ uint32_t word(uint32_t i) { return i < 64 ? rdl(hw[0], i) : rdl(hw[1], (i - 64) & 63); }
-    __device__ __forceinline__ uint32_t u32(uint32_t pos)
-    {
-        const uint32_t i = ((pos >> 3) - base) >> 2;
-        const uint32_t d0 = word(i), d1 = word(i + 1);
-        return (uint32_t)((((uint64_t)d1 << 32) | d0) >> (pos & 31));
-    }
-};
-
 // tables of one block (btype 1: the fixed code, 2: the code lengths in the stream at ip); returns a status
-template <class Bits>
-__device__ __forceinline__ int png_block_tables(Bits &B, InflateLds &L, uint32_t &ip, uint32_t btype, int lane)
+__device__ __forceinline__ int png_block_tables(Parser &P, InflateLds &L, uint32_t &ip, uint32_t btype, int lane)
 {
     uint8_t *const lens = hdr_lens(L); // lens[0 .. 288) literal/length, lens[288 .. 320) distance
     uint32_t hlit = 288, hdist = 32;
@@ -739,25 +696,21 @@ __device__ __forceinline__ int png_block_tables(Bits &B, InflateLds &L, uint32_t
     } else {
         uint8_t *const cl = hdr_cl(L);
         uint16_t *const scl = hdr_scl(L);
-        B.ensure(ip, lane);
-        if (ip + 14 > B.nbits)
+        if (ip + 14 > P.nbits)
             return ABUB_PNG_E_TRUNCATED;
-        const uint32_t hv = B.u32(ip);
+        const uint32_t hv = rfl(png_bits32(L, ip));
         hlit = (hv & 31) + 257;
         hdist = ((hv >> 5) & 31) + 1;
         const uint32_t hclen = ((hv >> 10) & 15) + 4;
         ip += 14;
         if (hlit > 286 || hdist > 30)
             return ABUB_PNG_E_SYMBOLS;
-        B.ensure(ip, lane);
+        png_ensure(P, L, ip, lane);
         if (lane < 32)
             cl[lane] = 0;
         wave_sync();
-        {
-            const uint64_t v57 = ((uint64_t)B.u32(ip + 32) << 32) | B.u32(ip); // the (at most 19) 3-bit lengths
-            if ((uint32_t)lane < hclen)
-                cl[png_cl_order[lane]] = (uint8_t)((v57 >> (3 * lane)) & 7);
-        }
+        if ((uint32_t)lane < hclen)
+            cl[png_cl_order[lane]] = (uint8_t)(png_bits32(L, ip + 3 * lane) & 7);
         wave_sync();
         ip += 3 * hclen;
         uint32_t cll[1] = {lane < 19 ? (uint32_t)cl[lane] : 0u};
@@ -778,8 +731,8 @@ __device__ __forceinline__ int png_block_tables(Bits &B, InflateLds &L, uint32_t
         const uint32_t total = hlit + hdist;
         uint32_t n = 0, prev = 0;
         while (n < total) {
-            B.ensure(ip, lane);
-            uint32_t v = B.u32(ip);
+            png_ensure(P, L, ip, lane);
+            uint32_t v = rfl(png_bits32(L, ip));
             const uint32_t idx = v & 127;
             const uint32_t ent = idx < 64 ? rdl(clt[0], idx) : rdl(clt[1], idx - 64);
             const uint32_t l = ent & 15, sym = ent >> 4;
@@ -812,7 +765,7 @@ __device__ __forceinline__ int png_block_tables(Bits &B, InflateLds &L, uint32_t
             prev = val;
             n += rep;
         }
-        if (ip > B.nbits)
+        if (ip > P.nbits)
             return ABUB_PNG_E_TRUNCATED;
     }
     wave_sync();
@@ -891,8 +844,7 @@ __device__ __forceinline__ int png_parse(Parser &P, InflateLds &L, Sink<TWO> &si
             continue;
         }
         {
-            RingBits B = {P, L, P.nbits};
-            const int rc = png_block_tables(B, L, ip, btype, lane);
+            const int rc = png_block_tables(P, L, ip, btype, lane);
             if (rc)
                 return rc;
         }
@@ -1117,419 +1069,6 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_png_inflate(const uint8_t *_
     }
 }
 
-
-// ---- three waves per stream ------------------------------------------------------------------------------------------
-//   lexer   owns the input ring: one token per bit offset for two windows at a time, speculatively, window after window
-//           (it never needs to know where the tokens really start, so nothing it does waits for the chain walk)
-//   walker  owns the stream position: block headers and tables, the chain walk over what the lexer found, end of block
-//   writer  owns the history ring: png_apply / png_apply_stored / png_apply_end as in the other kernels
-// One ring of PNG_NSLOT records in LDS: the lexer fills a record (q_head), the walker adds which offsets are tokens
-// (q_mid), the writer consumes it (q_tail).  Between blocks the walker parks the lexer (c_cmd / c_state), lets the records
-// the lexer produced beyond the end of the block pass as REC_SKIP, and is the producer itself for stored blocks, the end
-// and errors.  A wave's LDS operations execute in order, which is all the ordering the counters need.
-enum { REC_SKIP = 4 };
-enum { CMD_PARK = 0, CMD_RUN = 1, CMD_STOP = 2 };
-// a token as the lexer packs it: bits to advance (6) | kind (2) << 6 | literal byte << 8  or  (length - 3) << 8 | (distance - 1) << 16
-__device__ __forceinline__ uint32_t lex_pack(uint32_t nb, uint32_t kind, uint32_t tok)
-{
-    // tok as in TokSlot: literal = byte << 1; match = 1 | length << 1 | distance << 10
-    const uint32_t pay = (tok & 1) ? ((((tok >> 1) & 511u) - 3u) | (((tok >> 10) - 1u) << 8)) : ((tok >> 1) & 255u);
-    return (kind == T_BAD ? 1u : nb) | (kind << 6) | (pay << 8);
-}
-__device__ __forceinline__ uint32_t lex_tok(uint32_t w) // back to TokSlot's form
-{
-    const uint32_t pay = w >> 8;
-    return ((w >> 6) & 3) == T_LEN ? (1u | (((pay & 255u) + 3u) << 1) | ((((pay >> 8) & 32767u) + 1u) << 10)) : ((pay & 255u) << 1);
-}
-
-__global__ __launch_bounds__(192) void k_png_inflate3(const uint8_t *__restrict__ zbuf, const abub_png_frame *__restrict__ frames,
-                                                       uint32_t rawLen, uint64_t rawStride, uint8_t *__restrict__ rawbuf,
-                                                       int32_t *__restrict__ status)
-{
-    __shared__ InflateLds L;
-    const int f = blockIdx.x, lane = threadIdx.x & 63;
-    const uint32_t wave = rfl(threadIdx.x >> 6);
-    if (threadIdx.x == 0) {
-        L.q_head = L.q_mid = L.q_tail = 0;
-        L.q_abort = 0;
-        L.c_cmd = CMD_PARK;
-        L.c_state = 1; // parked
-        L.c_ip = 0;
-    }
-    __syncthreads();
-    if (status[f] != 0) // (refused by the gather kernel; the same for the whole workgroup)
-        return;
-    const abub_png_frame fr = frames[f];
-    const uint8_t *const z = zbuf + fr.zoff;
-    const uint32_t zpad = (fr.zlen + 15) & ~15u, nbits = fr.zlen * 8;
-
-    if (wave == 1) {
-        // ================================ the lexer ================================
-        Parser P;
-        P.z = z;
-        P.zlen = fr.zlen;
-        P.zpad = zpad;
-        P.nbits = nbits;
-        for (;;) {
-            // parked: wait for orders
-            uint32_t cmd, spins = 0;
-            while ((cmd = q_ld(&L.c_cmd)) == CMD_PARK) {
-                if (q_ld(&L.q_abort) || ++spins > PNG_SPINS)
-                    return;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (cmd == CMD_STOP)
-                return;
-            uint32_t ip = q_ld(&L.c_ip), head = q_ld(&L.q_head);
-            png_in_start(P, L, ip, lane);
-            uint32_t tail_pf = q_ld(&L.q_tail), cmd_pf = CMD_RUN;
-            for (;;) {
-                png_ensure(P, L, ip, lane);
-                const uint32_t pos = ip + lane, w = pos >> 5, sh = pos & 31;
-                uint32_t d[5];
-#pragma unroll
-                for (int k = 0; k < 5; ++k)
-                    d[k] = L.in[(w + k) & (PNG_INDW - 1)];
-                uint32_t lo[2], hi[2], e[2], de[2], w2[2], out[2];
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    lo[r] = __builtin_amdgcn_alignbit(d[2 * r + 1], d[2 * r], sh);
-                    hi[r] = __builtin_amdgcn_alignbit(d[2 * r + 2], d[2 * r + 1], sh);
-                    e[r] = L.lit[lo[r] & ((1u << LIT_ROOT) - 1)];
-                }
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const uint32_t nb2 = (e[r] & 15) + ((e[r] >> 6) & 15);
-                    w2[r] = __builtin_amdgcn_alignbit(hi[r], lo[r], nb2);
-                    de[r] = L.dist[w2[r] & ((1u << DIST_ROOT) - 1)];
-                }
-                // codes longer than the tables' index: every lane that has one (the lexer does not know which lanes the chain visits)
-                if (ballot(((e[0] | e[1]) >> 31) != 0 || ((((e[0] >> 4) & 3) == T_LEN) && (de[0] >> 31)) || ((((e[1] >> 4) & 3) == T_LEN) && (de[1] >> 31)))) {
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        if (e[r] >> 31) {
-                            e[r] = canon_slow<LIT_ROOT, false>(lo[r], L.cl, L.slit);
-                            const uint32_t nb2 = (e[r] & 15) + ((e[r] >> 6) & 15);
-                            w2[r] = __builtin_amdgcn_alignbit(hi[r], lo[r], nb2);
-                            de[r] = L.dist[w2[r] & ((1u << DIST_ROOT) - 1)];
-                        }
-                        if (((e[r] >> 4) & 3) == T_LEN && (de[r] >> 31))
-                            de[r] = canon_slow<DIST_ROOT, true>(w2[r], L.cd, L.sdist);
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const uint32_t lnb = e[r] & 15, eb = (e[r] >> 6) & 15, base = (e[r] >> 10) & 0x1fffffu;
-                    uint32_t kind = (e[r] >> 4) & 3;
-                    const uint32_t len = base + __builtin_amdgcn_ubfe(lo[r], lnb, eb);
-                    const uint32_t dnb = de[r] & 15, deb = (de[r] >> 6) & 15;
-                    const uint32_t dd = ((de[r] >> 10) & 0x1fffffu) + __builtin_amdgcn_ubfe(w2[r], dnb, deb);
-                    const bool isLen = kind == T_LEN;
-                    const uint32_t tok = isLen ? (1u | (len << 1) | (dd << 10)) : ((base & 255u) << 1);
-                    const uint32_t nb = isLen ? lnb + eb + dnb + deb : lnb;
-                    if (isLen && ((de[r] >> 4) & 3) == T_BAD)
-                        kind = T_BAD;
-                    out[r] = lex_pack(nb, kind, tok);
-                }
-                // room in the ring?  (tail_pf / cmd_pf were requested when the last record went out)
-                spins = 0;
-                while (head - tail_pf >= (uint32_t)PNG_NSLOT && cmd_pf == CMD_RUN) {
-                    tail_pf = q_ld(&L.q_tail);
-                    cmd_pf = q_ld(&L.c_cmd);
-                    if (head - tail_pf < (uint32_t)PNG_NSLOT)
-                        break;
-                    if (q_ld(&L.q_abort) || ++spins > PNG_SPINS)
-                        return;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (cmd_pf != CMD_RUN)
-                    break;
-                TokSlot &sl = L.q[head % PNG_NSLOT];
-                sl.tok[0][lane] = out[0];
-                sl.tok[1][lane] = out[1];
-                wave_sync();
-                ++head;
-                if (lane == 0)
-                    q_st(&L.q_head, head);
-                tail_pf = q_ld(&L.q_tail);
-                cmd_pf = q_ld(&L.c_cmd);
-                ip += 128;
-            }
-            if (cmd_pf == CMD_STOP)
-                return;
-            wave_sync();
-            if (lane == 0)
-                q_st(&L.c_state, 1u); // parked (after the last record's counter: in-order LDS)
-        }
-    }
-
-    if (wave == 2) {
-        // ================================ the writer ================================
-        Writer W;
-        W.z = z;
-        W.raw = rawbuf + (uint64_t)f * rawStride;
-        W.rawLen = rawLen;
-        W.op = W.op_r = W.fp = 0;
-        W.a1 = 1;
-        W.a2 = 0;
-        W.far = false;
-        uint32_t tail = 0;
-        int rc = 0;
-        for (;;) {
-            uint32_t spins = 0;
-            while (q_ld(&L.q_mid) == tail) {
-                if (++spins > PNG_SPINS) {
-                    rc = ABUB_PNG_E_INTERNAL;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (rc)
-                break;
-            wave_sync();
-            const TokSlot &sl = L.q[tail % PNG_NSLOT];
-            const uint32_t kind = rfl(sl.kind), aux = rfl(sl.aux);
-            const uint64_t valid[2] = {((uint64_t)rfl(sl.v[1]) << 32) | rfl(sl.v[0]), ((uint64_t)rfl(sl.v[3]) << 32) | rfl(sl.v[2])};
-            const uint32_t w0 = sl.tok[0][lane], w1 = sl.tok[1][lane];
-            wave_sync(); // (in-order LDS: the record's loads execute before the counter's store)
-            ++tail;
-            if (lane == 0)
-                q_st(&L.q_tail, tail);
-            const uint32_t k = kind & 7;
-            bool done = true;
-            if (k == REC_SKIP)
-                done = false;
-            else if (k == REC_TOKENS) {
-                const uint32_t tok[2] = {lex_tok(w0), lex_tok(w1)};
-                rc = png_apply(W, L, valid, tok, lane);
-                done = rc != 0;
-            } else if (k == REC_STORED) {
-                rc = png_apply_stored(W, L, aux, kind >> 3, lane);
-                done = rc != 0;
-            } else if (k == REC_END)
-                rc = png_apply_end(W, L, aux, lane);
-            else
-                rc = (int)aux;
-            if (done)
-                break;
-        }
-        if (lane == 0) {
-            status[f] = rc;
-            q_st(&L.q_abort, 1u);
-        }
-        return;
-    }
-
-    // ================================ the walker ================================
-    RegBits B;
-    B.z = z;
-    B.zpad = zpad;
-    B.nbits = nbits;
-    B.load(0, lane);
-    uint32_t mid = 0; // records passed on; while the lexer is parked also the number produced
-    bool gone = false; // the writer has set the status and left
-    // the walker as producer of a record (the lexer is parked): REC_STORED / REC_END / REC_ERROR
-    auto emit = [&](uint32_t kind, uint32_t aux) {
-        uint32_t spins = 0;
-        while (mid - q_ld(&L.q_tail) >= (uint32_t)PNG_NSLOT) {
-            if (q_ld(&L.q_abort) || ++spins > PNG_SPINS) {
-                gone = true;
-                return;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        TokSlot &sl = L.q[mid % PNG_NSLOT];
-        if (lane == 0) {
-            sl.kind = kind;
-            sl.aux = aux;
-        }
-        wave_sync();
-        ++mid;
-        if (lane == 0) {
-            q_st(&L.q_head, mid);
-            q_st(&L.q_mid, mid);
-        }
-    };
-    int err = 0;
-    uint32_t ip = 16;
-    if (fr.zlen < 6 || fr.zlen >= (1u << 28))
-        err = ABUB_PNG_E_TRUNCATED;
-    else {
-        const uint32_t h = B.u32(0);
-        const uint32_t cmf = h & 255, flg = (h >> 8) & 255;
-        if ((cmf & 15) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 || (flg & 0x20))
-            err = ABUB_PNG_E_HEADER;
-    }
-    bool final = false;
-    while (!err && !final && !gone) {
-        B.ensure(ip, lane);
-        if (ip + 3 > nbits) {
-            err = ABUB_PNG_E_TRUNCATED;
-            break;
-        }
-        uint32_t hv = B.u32(ip);
-        final = hv & 1;
-        const uint32_t btype = (hv >> 1) & 3;
-        ip += 3;
-        if (btype == 3) {
-            err = ABUB_PNG_E_BLOCKTYPE;
-            break;
-        }
-        if (btype == 0) {
-            ip = (ip + 7) & ~7u;
-            B.ensure(ip, lane);
-            if (ip + 32 > nbits) {
-                err = ABUB_PNG_E_TRUNCATED;
-                break;
-            }
-            hv = B.u32(ip);
-            const uint32_t len = hv & 0xffff;
-            if ((len ^ (hv >> 16)) != 0xffff) {
-                err = ABUB_PNG_E_STORED;
-                break;
-            }
-            ip += 32;
-            const uint32_t bp = ip >> 3;
-            if ((uint64_t)bp + len > fr.zlen) {
-                err = ABUB_PNG_E_TRUNCATED;
-                break;
-            }
-            if (len)
-                emit(REC_STORED | (len << 3), bp);
-            ip = (bp + len) * 8;
-            continue;
-        }
-        err = png_block_tables(B, L, ip, btype, lane);
-        if (err)
-            break;
-        // the lexer starts at ip
-        wave_sync();
-        if (lane == 0) {
-            q_st(&L.c_state, 0u);
-            q_st(&L.c_ip, ip);
-            q_st(&L.c_cmd, (uint32_t)CMD_RUN);
-        }
-        uint32_t s = 0, head_pf = mid;
-        bool eob = false;
-        while (!eob) {
-            uint32_t spins = 0;
-            while (head_pf == mid) {
-                head_pf = q_ld(&L.q_head);
-                if (head_pf != mid)
-                    break;
-                if (q_ld(&L.q_abort) || ++spins > PNG_SPINS) {
-                    gone = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (gone)
-                break;
-            wave_sync();
-            TokSlot &sl = L.q[mid % PNG_NSLOT];
-            const uint32_t w0 = sl.tok[0][lane], w1 = sl.tok[1][lane];
-            const uint32_t step0 = w0 & 63, step1 = w1 & 63, kind0 = (w0 >> 6) & 3, kind1 = (w1 >> 6) & 3;
-            uint64_t valid[2] = {0, 0};
-            uint32_t p = s;
-            do {
-                valid[0] |= 1ull << p;
-                p += rdl(step0, p);
-            } while (p < 64);
-            p -= 64;
-            do {
-                valid[1] |= 1ull << p;
-                p += rdl(step1, p);
-            } while (p < 64);
-            const uint64_t stop0 = ballot(((valid[0] >> lane) & 1) && kind0 >= T_EOB);
-            const uint64_t stop1 = ballot(((valid[1] >> lane) & 1) && kind1 >= T_EOB);
-            if (stop0 | stop1) {
-                if (stop0) {
-                    const uint32_t j = (uint32_t)__builtin_ctzll(stop0);
-                    if (rdl(kind0, j) == T_BAD) {
-                        err = ABUB_PNG_E_CODE;
-                        break;
-                    }
-                    valid[0] &= (1ull << j) - 1;
-                    valid[1] = 0;
-                    p = j + rdl(step0, j);
-                } else {
-                    const uint32_t j = (uint32_t)__builtin_ctzll(stop1);
-                    if (rdl(kind1, j) == T_BAD) {
-                        err = ABUB_PNG_E_CODE;
-                        break;
-                    }
-                    valid[1] &= (1ull << j) - 1;
-                    p = 64 + j + rdl(step1, j);
-                }
-                eob = true;
-            }
-            if (eob)
-                ip += p;
-            else {
-                ip += 128;
-                s = p - 64;
-            }
-            if (ip > nbits) {
-                err = ABUB_PNG_E_TRUNCATED;
-                break;
-            }
-            if (lane == 0) {
-                sl.v[0] = (uint32_t)valid[0];
-                sl.v[1] = (uint32_t)(valid[0] >> 32);
-                sl.v[2] = (uint32_t)valid[1];
-                sl.v[3] = (uint32_t)(valid[1] >> 32);
-                sl.kind = (valid[0] | valid[1]) ? (uint32_t)REC_TOKENS : (uint32_t)REC_SKIP;
-                sl.aux = 0;
-            }
-            wave_sync();
-            ++mid;
-            if (lane == 0)
-                q_st(&L.q_mid, mid);
-        }
-        // park the lexer; what it produced beyond the end of the block passes as REC_SKIP
-        if (lane == 0)
-            q_st(&L.c_cmd, (uint32_t)CMD_PARK);
-        for (uint32_t spins = 0;;) {
-            const uint32_t st = q_ld(&L.c_state); // (state first: the lexer stores its last counter before it)
-            const uint32_t hd = q_ld(&L.q_head);
-            while (mid != hd) {
-                if (lane == 0) {
-                    L.q[mid % PNG_NSLOT].kind = REC_SKIP;
-                    L.q[mid % PNG_NSLOT].aux = 0;
-                }
-                wave_sync();
-                ++mid;
-                if (lane == 0)
-                    q_st(&L.q_mid, mid);
-            }
-            if (st == 1)
-                break;
-            if (q_ld(&L.q_abort) || ++spins > PNG_SPINS) {
-                gone = true;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        if (err)
-            break;
-    }
-    if (!gone) {
-        if (!err) {
-            // the trailer: Adler-32 of the output, big-endian, at the next byte boundary
-            ip = (ip + 7) & ~7u;
-            B.ensure(ip, lane);
-            if (ip + 32 > nbits)
-                err = ABUB_PNG_E_TRUNCATED;
-            else
-                emit(REC_END, __builtin_bswap32(B.u32(ip)));
-        }
-        if (err)
-            emit(REC_ERROR, (uint32_t)err);
-    }
-    if (lane == 0)
-        q_st(&L.c_cmd, (uint32_t)CMD_STOP);
-}
-
 // ---- unfilter: one wave per frame, lanes along x, rows in order ----------------------------------------------------
 __device__ __forceinline__ uint32_t add4(uint32_t a, uint32_t b) // four byte-wise sums modulo 256
 {
@@ -1711,10 +1250,7 @@ extern "C" int abub_png_decode_dev(const uint8_t *files, size_t files_bytes, con
     // ABUB_PNG_WAVES=1: one wave parses and writes a stream; default: a parsing and a writing wave per stream
     static const bool oneWave = [] { const char *e = getenv("ABUB_PNG_WAVES"); return e && atoi(e) == 1; }();
     static const int dbg = [] { const char *e = getenv("ABUB_PNG_DEBUG"); return e ? atoi(e) : 0; }(); // (measurement only)
-    static const int waves = [] { const char *e = getenv("ABUB_PNG_WAVES"); return e ? atoi(e) : 0; }();
-    if (waves == 3 && !dbg)
-        k_png_inflate3<<<nframes, 192, 0, st>>>(zbuf, frames, (uint32_t)((size_t)H * ((size_t)W + 1)), (uint64_t)stride, rawbuf, status);
-    else if (oneWave || dbg)
+    if (oneWave || dbg)
         k_png_inflate<false><<<nframes, 64, 0, st>>>(zbuf, frames, (uint32_t)((size_t)H * ((size_t)W + 1)), (uint64_t)stride, rawbuf, status, dbg);
     else
         k_png_inflate<true><<<nframes, 128, 0, st>>>(zbuf, frames, (uint32_t)((size_t)H * ((size_t)W + 1)), (uint64_t)stride, rawbuf, status, 0);
