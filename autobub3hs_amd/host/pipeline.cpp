@@ -1441,6 +1441,9 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
         std::vector<StackMeta> meta;
         uint8_t *h_files = nullptr; // pinned; grown on demand by the reading thread (its worker's device is current there)
         size_t cap = 0, bytes = 0;
+        uint8_t *d_files = nullptr; // the reading thread uploads them as soon as they are read: the copy runs beside the GPU
+        size_t dcap = 0;            // work of the batch before
+        hipEvent_t uploaded = nullptr;
         std::vector<abub_png_frame> desc;        // the frames the GPU decodes
         std::vector<std::pair<int, int>> where;  // (stack, frame) of desc[i]
         std::vector<uint32_t> fileOff, fileLen;  // of desc[i] inside h_files
@@ -1453,7 +1456,7 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
         double ms = 0;
         long long bad = 0, hostGood = 0;
     };
-    auto readBatch = [&](int b, Encoded &out, uint8_t *h_host, int nthreads, int dev) {
+    auto readBatch = [&](int b, Encoded &out, uint8_t *h_host, int nthreads, int dev, hipStream_t upStream) {
         const double td = nowMs();
         (void)hipSetDevice(dev);
         const int e0 = b * G, nEv = std::min(G, (int)mine.size() - e0);
@@ -1614,6 +1617,23 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
         out.zbytes = zoff + 16;
         if (out.bytes >= ((size_t)1 << 32) || out.zbytes >= ((size_t)1 << 32))
             throw std::runtime_error("RunBatched: a batch of more than 4 GB of files (lower the batch size)");
+        if (!out.desc.empty()) {
+            if (out.bytes > out.dcap) {
+                if (out.d_files)
+                    (void)hipFree(out.d_files);
+                out.d_files = nullptr;
+                out.dcap = out.bytes + out.bytes / 4;
+                if (hipMalloc((void **)&out.d_files, out.dcap) != hipSuccess) {
+                    out.dcap = 0;
+                    throw std::runtime_error("RunBatched: hipMalloc of the uploaded files failed");
+                }
+            }
+            if (!out.uploaded && hipEventCreateWithFlags(&out.uploaded, hipEventDisableTiming) != hipSuccess)
+                throw std::runtime_error("RunBatched: hipEventCreate failed");
+            if (hipMemcpyAsync(out.d_files, out.h_files, out.bytes, hipMemcpyHostToDevice, upStream) != hipSuccess ||
+                hipEventRecord(out.uploaded, upStream) != hipSuccess)
+                throw std::runtime_error("RunBatched: upload of the files failed");
+        }
         out.ms = nowMs() - td;
     };
 
@@ -1655,11 +1675,12 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
         Decoded decd[2];
         Encoded encd[2]; // device-decode mode
         // device-decode mode: the uploaded files, the decoder's scratch, its descriptors (grown on demand)
-        uint8_t *d_files = nullptr, *d_z = nullptr, *d_raw = nullptr, *d_luts = nullptr;
+        uint8_t *d_z = nullptr, *d_raw = nullptr, *d_luts = nullptr;
+        hipStream_t upStream = nullptr;
         abub_png_frame *d_desc = nullptr;
         abub_png_seg *d_segs = nullptr;
         int32_t *d_status = nullptr, *h_status = nullptr;
-        size_t capFiles = 0, capZ = 0, capRaw = 0, capLuts = 0, capDesc = 0, capSegs = 0, capStatus = 0;
+        size_t capZ = 0, capRaw = 0, capLuts = 0, capDesc = 0, capSegs = 0, capStatus = 0;
         const int nthr = std::max(1, ndec / ngpus);
         std::thread dec;
         std::exception_ptr decErr[2];
@@ -1684,8 +1705,10 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
                 cap = need + need / 4 + 256;
                 HIPOK(hipMalloc(ptr, cap));
             };
-            if (devDecode)
+            if (devDecode) {
                 HIPOK(hipHostMalloc((void **)&h_status, (size_t)G * C * Fmax * sizeof(int32_t) + 64, hipHostMallocDefault));
+                HIPOK(hipStreamCreateWithFlags(&upStream, hipStreamNonBlocking));
+            }
             HIPOK(hipMalloc((void **)&d_model, 3 * (size_t)C * P)); // mu | sigma | sigma6
             uint8_t *d_mu = d_model, *d_sigma = d_model + (size_t)C * P, *d_s6 = d_model + 2 * (size_t)C * P;
             HIPOK(hipStreamCreateWithFlags(&copyStream, hipStreamNonBlocking));
@@ -1706,7 +1729,7 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
                 dec = std::thread([&, bb, sl, dev]() { // (dev by value: it lives inside the try block)
                     try {
                         if (devDecode)
-                            readBatch(bb, encd[sl], h_slab[sl], nthr, dev);
+                            readBatch(bb, encd[sl], h_slab[sl], nthr, dev, upStream);
                         else
                             decodeBatch(bb, h_slab[sl], decd[sl], nthr);
                     } catch (...) {
@@ -1748,19 +1771,18 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
                     std::vector<uint8_t> okGpu((size_t)nf, 0);
                     if (nf) {
                         const size_t stride = abub_png_raw_stride(W, H);
-                        grow((void **)&d_files, capFiles, E.bytes);
                         grow((void **)&d_z, capZ, E.zbytes);
                         grow((void **)&d_raw, capRaw, (size_t)nf * stride);
                         grow((void **)&d_desc, capDesc, (size_t)nf * sizeof(abub_png_frame));
                         grow((void **)&d_segs, capSegs, E.segs.size() * sizeof(abub_png_seg) + 8);
                         grow((void **)&d_luts, capLuts, E.luts.size() + 256);
                         grow((void **)&d_status, capStatus, (size_t)nf * sizeof(int32_t));
-                        HIPOK(hipMemcpyAsync(d_files, E.h_files, E.bytes, hipMemcpyHostToDevice, copyStream));
+                        HIPOK(hipStreamWaitEvent(copyStream, E.uploaded, 0)); // (the reading thread's upload of the files)
                         HIPOK(hipMemcpyAsync(d_desc, E.desc.data(), (size_t)nf * sizeof(abub_png_frame), hipMemcpyHostToDevice, copyStream));
                         HIPOK(hipMemcpyAsync(d_segs, E.segs.data(), E.segs.size() * sizeof(abub_png_seg), hipMemcpyHostToDevice, copyStream));
                         if (!E.luts.empty())
                             HIPOK(hipMemcpyAsync(d_luts, E.luts.data(), E.luts.size(), hipMemcpyHostToDevice, copyStream));
-                        check(abub_png_decode_dev(d_files, E.bytes, d_desc, nf, d_segs, (int)E.segs.size(), d_luts, (int)(E.luts.size() / 256), W,
+                        check(abub_png_decode_dev(E.d_files, E.bytes, d_desc, nf, d_segs, (int)E.segs.size(), d_luts, (int)(E.luts.size() / 256), W,
                                                   H, d_z, capZ, d_raw, capRaw, d_slab[slot], (size_t)nEv * perEvent, d_status, copyStream),
                               "abub_png_decode_dev");
                         HIPOK(hipMemcpyAsync(h_status, d_status, (size_t)nf * sizeof(int32_t), hipMemcpyDeviceToHost, copyStream));
@@ -1853,7 +1875,17 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
         }
         if (d_model)
             (void)hipFree(d_model);
-        for (void *q : {(void *)d_files, (void *)d_z, (void *)d_raw, (void *)d_luts, (void *)d_desc, (void *)d_segs, (void *)d_status})
+        if (upStream) {
+            (void)hipStreamSynchronize(upStream);
+            (void)hipStreamDestroy(upStream);
+        }
+        for (Encoded &E : encd) {
+            if (E.d_files)
+                (void)hipFree(E.d_files);
+            if (E.uploaded)
+                (void)hipEventDestroy(E.uploaded);
+        }
+        for (void *q : {(void *)d_z, (void *)d_raw, (void *)d_luts, (void *)d_desc, (void *)d_segs, (void *)d_status})
             if (q)
                 (void)hipFree(q);
         if (h_status)
