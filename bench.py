@@ -414,6 +414,7 @@ def main():
     # batches -> the same pipeline (what `abub3hs -z` does; reported in config only)
     if args.ingest_events > 0 and rank == 0 and world == 1:
         out["config"]["ingest_inclusive"] = ingest_inclusive(args, slab, pipe, E, C, F, W, H)
+        out["config"]["png_decode_on_gpu"] = png_decode_leg(torch, slab, C, F, W, H)
 
     # ---- dominant kernel alone, HIP events on the launch stream (roofline object) ---------------
     njobs = S * (F - 1)
@@ -515,6 +516,74 @@ def main():
     if dist:
         dist.barrier()  # all ranks leave together
         dist.destroy_process_group()
+
+
+def png_decode_leg(torch, slab, C, F, W, H):
+    """abub_png_decode_dev alone: one batch of 4 x CU-count encoded frames (what the inflate kernel runs at a time) resident
+    in HBM -> frames, timed with HIP events; the pixels are checked against the frames that were encoded."""
+    import io
+
+    import numpy as np
+    from PIL import Image
+
+    from autobub3hs_amd import _lib, hip
+
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    n = 4 * ncu
+    src = slab[0].cpu().numpy()  # [F, H, W] of stack 0
+    enc = []
+    for k in range(F):
+        b = io.BytesIO()
+        Image.fromarray(src[k]).save(b, format="PNG", compress_level=1)
+        enc.append(b.getvalue())
+    files = [enc[k % F] for k in range(n)]
+    frames_np = np.zeros((n, 8), dtype=np.uint32)
+    segs, blob, zoff, P = [], bytearray(), 0, W * H
+    for i, data in enumerate(files):
+        sg, _ = hip.png_parse(data, W, H)
+        base = len(blob)
+        zlen = sum(l for _, l in sg)
+        frames_np[i] = (len(segs), len(sg), zoff, zlen, 0xFFFFFFFF, 0, (i * P) & 0xFFFFFFFF, (i * P) >> 32)
+        segs += [(base + o, l) for o, l in sg]
+        blob += data
+        blob += b"\0" * ((-len(blob)) % 4)
+        zoff += ((zlen + 15) & ~15) + 16
+    blob += b"\0" * 8
+    dev = slab.device
+    d_files = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    d_frames = torch.from_numpy(frames_np.view(np.int32).copy()).to(dev)
+    d_segs = torch.tensor(segs, dtype=torch.int64).to(torch.int32).to(dev)
+    d_luts = torch.zeros(256, dtype=torch.uint8, device=dev)
+    stride = int(_lib.lib().abub_png_raw_stride(W, H))
+    d_z = torch.empty((zoff + 16,), dtype=torch.uint8, device=dev)
+    d_raw = torch.empty((n * stride,), dtype=torch.uint8, device=dev)
+    out = torch.zeros((n, H, W), dtype=torch.uint8, device=dev)
+    status = torch.zeros((n,), dtype=torch.int32, device=dev)
+
+    def go():
+        _lib.check(_lib.lib().abub_png_decode_dev(d_files.data_ptr(), d_files.numel(), d_frames.data_ptr(), n, d_segs.data_ptr(), len(segs),
+                                                  d_luts.data_ptr(), 0, W, H, d_z.data_ptr(), d_z.numel(), d_raw.data_ptr(), d_raw.numel(),
+                                                  out.data_ptr(), out.numel(), status.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   "abub_png_decode_dev")
+
+    go()
+    torch.cuda.synchronize()
+    assert int(status.abs().sum()) == 0, "abub_png_decode_dev refused a frame"
+    for k in (0, F - 1, n - 1):
+        assert torch.equal(out[k], slab[0, k % F]), "GPU PNG decode differs from the encoded frame"
+    ts = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        go()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ms = min(ts)
+    return {"frames_per_batch": n, "ms_per_batch": ms, "frames_per_s": n / ms * 1e3, "GBps_of_pixels": n * P / ms / 1e6,
+            "encoded_MB_per_frame": len(blob) / n / 1e6,
+            "note": "gather + inflate (a parsing and a writing wave per frame, 4 frames per CU) + unfilter on resident files; "
+                    "8-bit grey PNG, compress_level 1; the ingest figure above includes reading the archive, the upload and the detect stages"}
 
 
 def ingest_inclusive(args, slab, pipe, E, C, F, W, H):

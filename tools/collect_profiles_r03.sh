@@ -14,4 +14,14 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/k
 for f in $(find /tmp/kt_def -name '*kernel_stats.csv'); do head -1 $f > $O/bench_default_kernel_stats.csv; grep -E 'k2_|k3_|sus_|k1_|k4_|k_hist|k_pairs|k_slot|k1b|k_sigma|k_fill' $f >> $O/bench_default_kernel_stats.csv; done
 cd $R
 ./tools/rowload_bench 2000 0 copy > $O/copy_ceiling.jsonl 2>&1
+# GPU PNG decode alone (tools/png_bench.py): two waves per stream (default) and one, two compression levels, the real geometry
+{
+  for cfg in "1024 1" "1024 6" "1024 1 1680 1050"; do
+    for m in 2 1; do echo "waves=$m: $(ABUB_PNG_WAVES=$m timeout -k 10 300 python tools/png_bench.py $cfg 2>&1 | tail -1)"; done
+  done
+} > $O/png_bench.txt 2>&1
+cd /tmp; rm -rf /tmp/png_kt
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/png_kt -- python3 $R/tools/png_bench.py 1024 1 > $O/png_trace.log 2>&1
+for f in $(find /tmp/png_kt -name '*kernel_stats.csv'); do head -1 $f > $O/png_kernel_stats.csv; grep -E 'k_png' $f >> $O/png_kernel_stats.csv; done
+cd $R
 ls $O

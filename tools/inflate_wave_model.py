@@ -8,6 +8,9 @@ the same phases and the same tables, so the algorithm can be checked against zli
   iteration's first match are copied by their own lanes, the others (dependent / overlapping / long) one after the other
   by the whole wave.
 
+The kernel differs in engineering, not in the algorithm: two windows per iteration, table entries that carry base and
+extra-bit count, long codes resolved only when the chain visits their lane, a parsing and a writing wave per stream.
+
 Usage: python tools/inflate_wave_model.py file.png [...]   (compares with zlib.decompress, prints token statistics)"""
 import struct
 import sys

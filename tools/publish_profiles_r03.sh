@@ -9,3 +9,4 @@ cp $S/pmc_bench/kernel_trace_abub.csv $D/bench_inflight1_kernel_trace_abub.csv
 cp $S/pmc_bench_1680/bench_pmc_summary.json $D/bench_1680x1050_pmc_summary.json
 cp $S/pmc_bench_1680/kernel_stats.csv $D/bench_1680x1050_inflight1_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE SQ_WAVE_CYCLES TCC_HIT_sum SQ_INSTS_VMEM_RD; do cp $S/pmc_bench/pmc_$c.csv $D/bench_pmc_$c.csv; done
+cp $S/png_bench.txt $S/png_kernel_stats.csv $D/
