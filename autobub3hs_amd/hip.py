@@ -229,10 +229,10 @@ def png_decode(files, W, H, device="cuda:0"):
         zoff += ((zlen + 15) & ~15) + 16
     blob += b"\0" * 8
     dev = torch.device(device)
-    d_files = torch.frombuffer(bytes(blob), dtype=torch.uint8).to(dev)
+    d_files = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
     d_frames = torch.from_numpy(frames_np.view(np.int32).copy()).to(dev)
     d_segs = torch.tensor(segs if segs else [(0, 0)], dtype=torch.int64).to(torch.int32).to(dev) if True else None
-    d_luts = torch.frombuffer(b"".join(luts) if luts else bytes(256), dtype=torch.uint8).to(dev)
+    d_luts = torch.frombuffer(bytearray(b"".join(luts) if luts else bytes(256)), dtype=torch.uint8).to(dev)
     stride = int(_lib.lib().abub_png_raw_stride(W, H))
     d_z = torch.empty((max(zoff, 16),), dtype=torch.uint8, device=dev)
     d_raw = torch.empty((max(n, 1) * stride,), dtype=torch.uint8, device=dev)

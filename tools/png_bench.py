@@ -49,7 +49,7 @@ for i, data in enumerate(files):
     zoff += ((zlen + 15) & ~15) + 16
 blob += b"\0" * 8
 dev = torch.device("cuda:0")
-d_files = torch.frombuffer(bytes(blob), dtype=torch.uint8).to(dev)
+d_files = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
 d_frames = torch.from_numpy(frames_np.view(np.int32).copy()).to(dev)
 d_segs = torch.tensor(segs, dtype=torch.int64).to(torch.int32).to(dev)
 d_luts = torch.zeros(256, dtype=torch.uint8, device=dev)
