@@ -1558,10 +1558,14 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
                         t.state = 2;
                         continue;
                     }
-                    if (!pngWalk(dst, (size_t)t.size, W, H, t.info)) {
-                        // not a file for the GPU decoder (BMP, 16-bit, colour, interlaced, another size): the host decoder's answer
-                        t.pix.resize(P);
-                        t.state = cv::imdecodeInto(dst, (size_t)t.size, t.pix.data(), W, H) ? 1 : 2;
+                    try {
+                        if (!pngWalk(dst, (size_t)t.size, W, H, t.info)) {
+                            // not a file for the GPU decoder (BMP, 16-bit, colour, interlaced, another size): the host decoder's answer
+                            t.pix.resize(P);
+                            t.state = cv::imdecodeInto(dst, (size_t)t.size, t.pix.data(), W, H) ? 1 : 2;
+                        }
+                    } catch (...) { // (an allocation that fails inside a pool thread must not end the process)
+                        t.state = 2;
                     }
                 }
             });
