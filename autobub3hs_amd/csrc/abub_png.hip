@@ -631,7 +631,8 @@ struct Sink {
     uint32_t head;  // TWO
     uint32_t tail_pf; // TWO: the consumer's counter as last seen
     int lane;
-    int dbg;        // measurement only: 1 = the records are dropped (what the parsing alone costs)
+    int dbg;        // measurement only (ABUB_PNG_DEBUG): 1 = the records are dropped (what the parsing alone costs), 2 = no match
+                    // copies, 3 = no stores at all, 4 = no chain walk, 5 = two waves, the status carries the queue's hand-over latency
     // returns a status for !TWO; for TWO: 0, or -1 when the writing wave has gone (the parser then just stops)
     __device__ __forceinline__ int put(uint32_t kind, uint32_t aux, const uint64_t (&valid)[2], const uint32_t (&tok)[2])
     {
@@ -666,7 +667,7 @@ struct Sink {
             sl.v[2] = (uint32_t)valid[1];
             sl.v[3] = (uint32_t)(valid[1] >> 32);
             sl.kind = kind;
-            sl.aux = aux;
+            sl.aux = (dbg == 5 && (kind & 3) == REC_TOKENS) ? (uint32_t)__builtin_readcyclecounter() : aux;
         }
         // (a wave's LDS operations execute in order: the counter's store follows the record's without waiting for them)
         wave_sync();
@@ -1027,6 +1028,8 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_png_inflate(const uint8_t *_
     // the writing wave
     uint32_t tail = 0;
     int rc = 0;
+    uint64_t latSum = 0; // dbg == 5: cycles between a record's publication and its pick-up, over the pick-ups that had waited
+    uint32_t latN = 0;
     for (;;) {
         uint32_t spins = 0;
         while (q_ld(&L.q_head) == tail) {
@@ -1043,6 +1046,10 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_png_inflate(const uint8_t *_
         const uint32_t kind = rfl(sl.kind), aux = rfl(sl.aux);
         const uint64_t valid[2] = {((uint64_t)rfl(sl.v[1]) << 32) | rfl(sl.v[0]), ((uint64_t)rfl(sl.v[3]) << 32) | rfl(sl.v[2])};
         const uint32_t tok[2] = {sl.tok[0][lane], sl.tok[1][lane]};
+        if (dbg == 5 && spins > 0 && (kind & 3) == REC_TOKENS) {
+            latSum += (uint32_t)((uint32_t)__builtin_readcyclecounter() - aux);
+            ++latN;
+        }
         // (the record is in registers: the slot may be refilled while its tokens are applied)
         wave_sync(); // (in-order LDS: the slot's loads execute before the counter's store)
         ++tail;
@@ -1064,7 +1071,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_png_inflate(const uint8_t *_
             break;
     }
     if (lane == 0) {
-        status[f] = rc;
+        status[f] = (dbg == 5 && rc == 0) ? -(int)(latN ? latSum / latN : 0) - 1000000 * (int)min(latN / 1000u, 2000u) : rc;
         q_st(&L.q_abort, 1u);
     }
 }
@@ -1250,10 +1257,10 @@ extern "C" int abub_png_decode_dev(const uint8_t *files, size_t files_bytes, con
     // ABUB_PNG_WAVES=1: one wave parses and writes a stream; default: a parsing and a writing wave per stream
     static const bool oneWave = [] { const char *e = getenv("ABUB_PNG_WAVES"); return e && atoi(e) == 1; }();
     static const int dbg = [] { const char *e = getenv("ABUB_PNG_DEBUG"); return e ? atoi(e) : 0; }(); // (measurement only)
-    if (oneWave || dbg)
+    if ((oneWave || dbg) && dbg != 5)
         k_png_inflate<false><<<nframes, 64, 0, st>>>(zbuf, frames, (uint32_t)((size_t)H * ((size_t)W + 1)), (uint64_t)stride, rawbuf, status, dbg);
     else
-        k_png_inflate<true><<<nframes, 128, 0, st>>>(zbuf, frames, (uint32_t)((size_t)H * ((size_t)W + 1)), (uint64_t)stride, rawbuf, status, 0);
+        k_png_inflate<true><<<nframes, 128, 0, st>>>(zbuf, frames, (uint32_t)((size_t)H * ((size_t)W + 1)), (uint64_t)stride, rawbuf, status, dbg);
     const int ndw = (W + 255) / 256;
 #define UNF(N)                                                                                                             \
     k_png_unfilter<N><<<nframes, 64, 0, st>>>(rawbuf, (uint64_t)stride, frames, luts, (uint32_t)nluts, W, H, out,         \

@@ -77,4 +77,8 @@ for r in range(3):
     torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1))
 ms = min(ts)
+if os.environ.get("ABUB_PNG_DEBUG") == "5":
+    stv = status.cpu().numpy().astype(np.int64)
+    print("hand-over probe: mean pick-up latency (cycles, s_memtime) over the waits:", float(np.mean((-stv) % 1000000)), "waits per stream (thousands):",
+          float(np.mean((-stv) // 1000000)))
 print(f"{n} frames {W}x{H} level {level}: {ms:.2f} ms per batch = {n / ms * 1e3:.0f} frames/s, {n * P / ms / 1e6:.1f} GB/s of pixels; all: {[round(t, 2) for t in ts]}")
