@@ -205,6 +205,20 @@ def imdecode(data, cap=1 << 22):
     return out[: w.value * h.value].reshape(h.value, w.value).copy()
 
 
+def png_walk(data, W, H, cap=4096):
+    """host/pngwalk.hpp::pngWalk: None for a file the GPU decoder does not take, else (IDAT segments [(offset, length)],
+    palette -> grey table (bytes) or None)"""
+    L = lib()
+    L.abh_png_walk.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_int, _ip, _ip, _u8p]
+    src = np.frombuffer(data, np.uint8)
+    segs = (C.c_uint32 * (2 * cap))()
+    n, pal = C.c_int(), C.c_int()
+    lut = np.zeros(256, np.uint8)
+    if not L.abh_png_walk(src.ctypes.data_as(_u8p), len(src), W, H, segs, cap, C.byref(n), C.byref(pal), lut.ctypes.data_as(_u8p)):
+        return None
+    return [(segs[2 * i], segs[2 * i + 1]) for i in range(min(n.value, cap))], (lut.tobytes() if pal.value else None)
+
+
 def imwrite(path, img):
     """cvlite's cv::imwrite (debug image write-out): 8-bit grey PNG, or BMP when the name ends in .bmp."""
     L = lib()

@@ -21,6 +21,7 @@
 #include "devctx.hpp"
 #include "driver.hpp"
 #include "hostlogic.hpp"
+#include "pngwalk.hpp"
 #include "runbatch.hpp"
 
 namespace {
@@ -182,6 +183,25 @@ int abh_imdecode(const uint8_t *data, int n, uint8_t *out, int cap, int *w, int 
 }
 
 // cv::imwrite of the debug write-out (PNG, or BMP by extension)
+// pngWalk (host/pngwalk.hpp: what RunBatched learns about a file before the GPU decodes it): 1 = a W x H 8-bit grey / palette PNG
+// (segs_out: up to cap (offset, length) pairs of its IDAT chunks, *nsegs their number, *palette, lut_out[256]), 0 = a file
+// for the host decoder
+int abh_png_walk(const uint8_t *data, int n, int W, int H, uint32_t *segs_out, int cap, int *nsegs, int *palette, uint8_t *lut_out)
+{
+    abub::PngInfo info;
+    if (!abub::pngWalk(data, (size_t)n, W, H, info))
+        return 0;
+    *nsegs = (int)info.segs.size();
+    for (int i = 0; i < (int)info.segs.size() && i < cap; ++i) {
+        segs_out[2 * i] = info.segs[i].off;
+        segs_out[2 * i + 1] = info.segs[i].len;
+    }
+    *palette = info.palette ? 1 : 0;
+    if (info.palette)
+        std::memcpy(lut_out, info.lut, 256);
+    return 1;
+}
+
 int abh_imwrite(const char *path, const uint8_t *img, int W, int H)
 {
     cv::Mat m(H, W, CV_8U);

@@ -274,6 +274,42 @@ def test_batched_run_with_frames_decoded_on_the_gpu(tmp_path, monkeypatch):
     assert st["frames_host_decoded"] >= 2 * 2 * F - 3, st
 
 
+def test_png_walk_for_the_gpu_decoder():
+    """What RunBatched's reading threads find out about a file (host/pngwalk.hpp): the IDAT chunks and the palette table of
+    8-bit grey / palette PNGs of the run's geometry; everything else is left to the host decoder.  The Python helper of the
+    GPU tests (hip.png_parse) must say the same."""
+    import io
+
+    from autobub3hs_amd import hip
+
+    rs = np.random.RandomState(3)
+    W, H = 64, 20
+    img = rs.randint(0, 256, (H, W)).astype(np.uint8)
+
+    def png(im, **kw):
+        b = io.BytesIO()
+        im.save(b, format="PNG", **kw)
+        return b.getvalue()
+
+    grey = png(Image.fromarray(img))
+    segs, lut = host.png_walk(grey, W, H)
+    assert lut is None and len(segs) >= 1 and (segs, lut) == hip.png_parse(grey, W, H)
+    o, n = segs[0]
+    assert grey[o - 4:o] == b"IDAT" and int.from_bytes(grey[o - 8:o - 4], "big") == n
+    pal = png(Image.fromarray(img).convert("P"))
+    segs, lut = host.png_walk(pal, W, H)
+    assert lut is not None and (segs, lut) == hip.png_parse(pal, W, H)
+    sample = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sample_40l19_cam1_image30.png"), "rb").read()
+    segs, lut = host.png_walk(sample, 1680, 1050)
+    assert len(segs) == 15 and lut == bytes(range(256)) and (segs, lut) == hip.png_parse(sample, 1680, 1050)
+    assert host.png_walk(sample, 1680, 1048) is None  # another geometry
+    for other in (png(Image.fromarray(img.astype(np.uint16) << 8)), png(Image.fromarray(np.stack([img] * 3, -1))), b"BM" + bytes(60),
+                  grey[:40], b"", png(Image.fromarray(img), compress_level=0)[:-20]):
+        assert (host.png_walk(other, W, H) is None) == (hip.png_parse(other, W, H) is None)
+    assert host.png_walk(png(Image.fromarray(img.astype(np.uint16) << 8)), W, H) is None
+    assert host.png_walk(grey[:40], W, H) is None
+
+
 @pytest.mark.parametrize("ext", ["png", "bmp"])
 def test_imwrite_round_trip(tmp_path, ext):
     """Debug image write-out (AnalyzerUnit.cpp:237, L3Localizer.cpp:236-257): what cvlite writes, Pillow and cvlite's
