@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Ingestion-inclusive rate of the batched path (zip archive of PNGs -> ZipParser -> decode threads -> pinned batches -> GPU
-pipeline) for several decode-thread counts; the archive is written once.
+"""Ingestion-inclusive rate of the batched path (zip archive of PNGs -> ZipParser -> files uploaded and decoded on the GPU, or
+with ABUB_GPU_DECODE=0 decode threads -> pinned batches -> GPU pipeline) for several reading / decode-thread counts; the archive
+is written once.
 usage: python3 tools/ingest_bench.py [--events 96] [--width 1280 --height 1024] threads [threads ...]"""
 import argparse, io, json, os, shutil, sys, tempfile, time, zipfile
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -56,7 +57,8 @@ try:
             dt = time.perf_counter() - t2
             print(json.dumps({"decode_threads": nt, "frames_per_s": round(E * C * F / dt), "detect_total_s": round(dt, 3),
                               "decode_s": round(st["decode_s"], 3), "gpu_s": round(st["gpu_s"], 3), "list_s": round(st["list_s"], 3),
-                              "batches": int(st["batches"]), "train_s": round(t_train, 2)}), flush=True)
+                              "batches": int(st["batches"]), "train_s": round(t_train, 2), "frames_decoded_on_gpu": int(st["frames_gpu_decoded"]),
+                              "gpu_decode_s": round(st["gpudecode_s"], 3)}), flush=True)
     run.close()
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
