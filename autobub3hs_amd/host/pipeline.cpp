@@ -1669,8 +1669,13 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
             }
             check(abub_sigma6_dev(d_sigma, d_s6, (size_t)C * P, copyStream), "abub_sigma6_dev");
             HIPOK(hipStreamSynchronize(copyStream));
+            const bool trace = getenv("ABUB_INGEST_TRACE") != nullptr;
+            if (trace)
+                fprintf(stderr, "worker %d: buffers and model on the device at %.1f ms\n", g, nowMs() - tAll);
             RunPipeline pipe(dev, W, H, Fmax, G, C, tss.data(), std::max(1, opt.hostThreads), opt.maskDir.c_str());
             pipe.d_sigmaRaw = d_sigma;
+            if (trace)
+                fprintf(stderr, "worker %d: pipeline of %d events ready at %.1f ms\n", g, G, nowMs() - tAll);
             int slot = 0;
             // (an exception of the look-ahead thread -- a failed allocation, a throwing parser -- is carried over and re-thrown here)
             auto startDecode = [&](int bb, int sl) {
@@ -1688,8 +1693,22 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
             };
             if (g < nb)
                 startDecode(g, slot);
+            if (devDecode) {
+                // (the decoder's scratch while the first batch's files are being read: sizes from the batch's frame count; the
+                // stream buffer from a guess that regrows if a batch proves it wrong)
+                const size_t nfMax = (size_t)std::max(1, Ggpu) * C * Fmax;
+                grow((void **)&d_raw, capRaw, nfMax * abub_png_raw_stride(W, H));
+                grow((void **)&d_desc, capDesc, nfMax * sizeof(abub_png_frame));
+                grow((void **)&d_status, capStatus, nfMax * sizeof(int32_t));
+                grow((void **)&d_z, capZ, nfMax * (P / 4 * 3));
+                if (trace)
+                    fprintf(stderr, "worker %d: decoder scratch ready at %.1f ms\n", g, nowMs() - tAll);
+            }
             for (int b = g; b < nb; b += ngpus) {
+                const double tj = nowMs();
                 dec.join();
+                if (trace)
+                    fprintf(stderr, "batch %d: waited %.1f ms for its files at %.1f ms\n", b, nowMs() - tj, nowMs() - tAll);
                 if (decErr[slot])
                     std::rethrow_exception(decErr[slot]);
                 const int bn = b + ngpus;
@@ -1766,7 +1785,7 @@ int RunBatched(Parser *parser, const std::vector<std::string> &EventList, const 
                     }
                     onHost += E.hostGood;
                     pngms = nowMs() - tp;
-                    if (getenv("ABUB_INGEST_TRACE"))
+                    if (trace)
                         fprintf(stderr, "batch %d: %d frames for the GPU (%zu MB of files), %lld decoded by host threads, read + host decode %.1f ms, "
                                         "upload + GPU decode %.1f ms\n", b, nf, E.bytes >> 20, E.hostGood, E.ms, pngms);
                     dms = E.ms;
