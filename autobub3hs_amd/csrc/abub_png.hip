@@ -30,7 +30,13 @@ constexpr int PNG_CAP = 512;     // output bytes one pass over a record's tokens
 constexpr int PNG_RING = PNG_WIN + PNG_CAP;
 constexpr int PNG_INDW = 128;    // input ring in dwords (512 B, refilled 256 B at a time, one refill prefetched in registers)
 constexpr int PNG_NSLOT = 2;     // token records in flight between the parsing and the writing wave
-constexpr int PNG_FLUSH = 2048;  // unflushed output that triggers a flush
+#ifndef PNG_FLUSH_BYTES
+#define PNG_FLUSH_BYTES 2048
+#endif
+#ifndef PNG_SLEEP
+#define PNG_SLEEP 1
+#endif
+constexpr int PNG_FLUSH = PNG_FLUSH_BYTES;  // unflushed output that triggers a flush (a tuning macro, like PNG_SLEEP below)
 constexpr int LIT_ROOT = 10, DIST_ROOT = 8;
 constexpr int PNG_SHORT = 8;     // matches up to this length are copied by their own lane
 
@@ -656,7 +662,7 @@ struct Sink {
                 break;
             if (q_ld(&L.q_abort) || ++spins > PNG_SPINS)
                 return -1;
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(PNG_SLEEP);
         }
         TokSlot &sl = L.q[head % PNG_NSLOT];
         sl.tok[0][lane] = tok[0];
@@ -1037,7 +1043,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void k_png_inflate(const uint8_t *_
                 rc = ABUB_PNG_E_INTERNAL;
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(PNG_SLEEP);
         }
         if (rc)
             break;
